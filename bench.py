@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json config 2.
+
+  1024-channel bank of 8th-order IIR band-pass (butterworth(4, 0.3, 0.6): na = nb = 9),
+  float64, 2^20 samples per channel resident in HBM, streamed in 64K-sample blocks with the
+  filter state carried on the device between blocks.
+
+One STEP = one RTFilterBank_updaten call = one 65 536-sample block for all 1024 channels of this
+rank's bank (512 MiB read + 512 MiB written).  Steps walk the 16 blocks of the stream in order;
+when the stream wraps the bank is RTFilter_reset (inside the timed region).
+
+N GPUs: one process per GPU (torch.distributed / RCCL only for the barrier and the max-reduce of the
+time; the path has no data-path collective).  The bank is channel-sharded: rank r owns channels
+[r*1024, (r+1)*1024) => weak scaling; value = samples all ranks filtered / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CHANNELS = 1024
+STREAM = 1 << 20
+BLOCK = 1 << 16
+NBLOCKS = STREAM // BLOCK
+SEED = 0x5EED0002
+DESIGN = "bw4_bp_0.3_0.6"
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_SAMPLE = 16            # 8 B read x + 8 B write y
+
+
+def cpu_baseline(b, a):
+    """Reference (oracle/_ref, if it travelled) or the oracle port, on the host cores: every thread
+    filters CHANNELS/threads channels of 2^20 samples with its own filter object."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from oracle import ref
+    from tests import util
+    threads = max(1, min(16, os.cpu_count() or 1))
+    per_thread = max(1, CHANNELS // threads // 4)     # bounded sample: a quarter of one stream pass
+    kind = "reference" if ref.available() else "port"
+    xs = [util.synth(SEED, t, 0, STREAM) for t in range(threads)]
+
+    def work(t):
+        for _ in range(per_thread):
+            if kind == "reference":
+                ref.RefIIR(b, a).updaten(xs[t])
+            else:
+                orc.iir(b, a).updaten(xs[t])
+
+    work(0) if per_thread == 1 else None
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    nsamp = threads * per_thread * STREAM
+    return dict(value=nsamp / dt / 1e6, unit="Msamples/s", cores=threads, kind=kind,
+                sample="%d channels x 2^20 samples of config 2 (%s), RTFilter_updaten per channel, "
+                       "%d host threads, %.1f s" % (threads * per_thread, DESIGN, threads, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--mode", choices=["auto", "scan", "seq"], default="auto")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from dsp_amd import bank as gbank
+    from tests import util
+    _, b, a = util.design_coefs(DESIGN)
+    mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_SCAN, seq=gbank.MODE_SEQUENTIAL)[args.mode]
+    bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
+
+    x = torch.empty((CHANNELS, STREAM), dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    gbank.synth_fill(x, SEED, chan0=rank * CHANNELS, n0=0)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    step_no = [0]
+
+    def step(ev=None):
+        j = step_no[0] % NBLOCKS
+        if j == 0 and step_no[0] > 0:
+            bank.reset(stream)
+        if ev is not None:
+            ev[0].record(stream)
+        bank.updaten_ptr(y.data_ptr() + j * BLOCK * 8, STREAM, x.data_ptr() + j * BLOCK * 8, STREAM,
+                         BLOCK, stream)
+        if ev is not None:
+            ev[1].record(stream)
+        step_no[0] += 1
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+
+    if rank == 0:
+        samples_per_step = CHANNELS * BLOCK
+        value = world * samples_per_step * args.steps / elapsed / 1e6
+        achieved = samples_per_step * BYTES_PER_SAMPLE / kern_avg_s / 1e9
+        line = {
+            "metric": "filtered Msamples/s (whole node)", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 2: 1024-channel 8th-order IIR band-pass bank "
+                                   "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
+                                   "64K-sample blocks, state carried in HBM",
+                       "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
+                       "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(b, a)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""FilterBank: many RTFilter channels advanced together on an MI355X.
+
+Thin host mirror of include/RTFilterBank.h.  Semantics are the reference's
+per-filter loop (python/dsp.py:25-34 -> RTFilter_updaten, src/RTFilter.c:111-119)
+applied to every channel of the bank; samples stay in device memory.
+
+torch is used only as the owner of device buffers and streams: tensors are
+passed to the C ABI as raw pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import cdsp
+from .cdsp import dspdll
+
+KIND_IIR, KIND_FIR, KIND_FIR_PARTIAL = cdsp.RTFB_KIND_IIR, cdsp.RTFB_KIND_FIR, cdsp.RTFB_KIND_FIR_PARTIAL
+MODE_AUTO, MODE_SEQUENTIAL, MODE_SCAN = cdsp.RTFB_MODE_AUTO, cdsp.RTFB_MODE_SEQUENTIAL, cdsp.RTFB_MODE_SCAN
+
+
+class DSPError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = dspdll.RTFilterBank_last_error() or b""
+        super().__init__("%s failed with status %d: %s" % (where, status, msg.decode()))
+
+
+def _check(status, where):
+    if status != cdsp.RTFB_OK:
+        raise DSPError(status, where)
+
+
+def device_count():
+    return dspdll.dsp_device_count()
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:
+            pass
+        return None
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+def iir_design(b, a):
+    return dict(kind=KIND_IIR, b=np.ascontiguousarray(b, dtype=np.float64),
+                a=np.ascontiguousarray(a, dtype=np.float64))
+
+
+def fir_design(b, partial=False):
+    return dict(kind=KIND_FIR_PARTIAL if partial else KIND_FIR,
+                b=np.ascontiguousarray(b, dtype=np.float64), a=None)
+
+
+class FilterBank:
+    """nch channels; channel c runs designs[design_of_channel[c]]."""
+
+    def __init__(self, designs, design_of_channel, device=0, mode=MODE_AUTO):
+        self._handle = C.c_void_p()
+        self.device = device
+        self._keep = designs                      # coefficient arrays stay alive during the call
+        arr = (cdsp.RTFilterDesign_ * len(designs))()
+        for i, d in enumerate(designs):
+            arr[i].kind = d["kind"]
+            arr[i].nb = len(d["b"])
+            arr[i].b = d["b"].ctypes.data_as(C.POINTER(C.c_double))
+            if d["kind"] == KIND_IIR:
+                arr[i].na = len(d["a"])
+                arr[i].a = d["a"].ctypes.data_as(C.POINTER(C.c_double))
+        idx = np.ascontiguousarray(design_of_channel, dtype=np.int32)
+        _check(dspdll.RTFilterBank_from_designs(C.byref(self._handle), arr, len(designs),
+                                                idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
+                                                device), "RTFilterBank_from_designs")
+        self.nch = len(idx)
+        self._filters = None
+        if mode != MODE_AUTO:
+            self.set_mode(mode)
+
+    @classmethod
+    def from_filters(cls, filters, device=0, mode=MODE_AUTO):
+        """filters: dsp.RTIIRFilter / dsp.RTFIRFilter objects (their C structs are referenced)."""
+        self = cls.__new__(cls)
+        self._handle = C.c_void_p()
+        self.device = device
+        self._filters = list(filters)
+        ptrs = (C.c_void_p * len(self._filters))(*[C.addressof(f.cobj()) for f in self._filters])
+        _check(dspdll.RTFilterBank_from_filters(C.byref(self._handle), ptrs, len(self._filters), device),
+               "RTFilterBank_from_filters")
+        self.nch = len(self._filters)
+        self._keep = None
+        if mode != MODE_AUTO:
+            self.set_mode(mode)
+        return self
+
+    def close(self):
+        if self._handle:
+            dspdll.RTFilterBank_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, mode):
+        _check(dspdll.RTFilterBank_set_mode(self._handle, mode), "RTFilterBank_set_mode")
+
+    def updaten_ptr(self, out_ptr, ld_out, in_ptr, ld_in, n, stream=None):
+        _check(dspdll.RTFilterBank_updaten(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
+                                           ld_in, n, _stream_ptr(stream)), "RTFilterBank_updaten")
+
+    def __call__(self, x, out=None, stream=None):
+        """x: (nch, n) float64 device tensor with contiguous rows.  Returns the output tensor."""
+        import torch
+        assert x.dtype == torch.float64 and x.dim() == 2 and x.shape[0] == self.nch
+        assert x.stride(1) == 1 or x.shape[1] <= 1
+        if out is None:
+            out = torch.empty_like(x, memory_format=torch.contiguous_format)
+        assert out.shape == x.shape and out.dtype == torch.float64
+        self.updaten_ptr(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), x.shape[1], stream)
+        return out
+
+    def reset(self, stream=None):
+        _check(dspdll.RTFilterBank_reset(self._handle, _stream_ptr(stream)), "RTFilterBank_reset")
+
+    def sync_to_host(self, stream=None):
+        _check(dspdll.RTFilterBank_sync_to_host(self._handle, _stream_ptr(stream)), "RTFilterBank_sync_to_host")
+
+    @property
+    def state_ld(self):
+        return dspdll.RTFilterBank_state_ld(self._handle)
+
+    def get_state(self, stream=None):
+        ld = self.state_ld
+        st = np.empty((self.nch, ld), dtype=np.float64)
+        fv = np.empty(self.nch, dtype=np.float64)
+        ini = np.empty(self.nch, dtype=np.int32)
+        _check(dspdll.RTFilterBank_get_state(self._handle, st.ctypes.data_as(C.POINTER(C.c_double)),
+                                             fv.ctypes.data_as(C.POINTER(C.c_double)),
+                                             ini.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream)),
+               "RTFilterBank_get_state")
+        return st, fv, ini
+
+    def set_state(self, state=None, fval=None, init=None, stream=None):
+        def ptr(a, t, ct):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=t)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(ct))
+        keep = []
+        if state is not None:
+            assert np.shape(state) == (self.nch, self.state_ld)
+        _check(dspdll.RTFilterBank_set_state(self._handle, ptr(state, np.float64, C.c_double),
+                                             ptr(fval, np.float64, C.c_double),
+                                             ptr(init, np.int32, C.c_int32), _stream_ptr(stream)),
+               "RTFilterBank_set_state")
+
+
+def synth_fill(tensor, seed, chan0=0, n0=0, stream=None):
+    """Fill a (nch, n) float64 device tensor with the SURVEY.md 8(d) synthetic input."""
+    nch, n = tensor.shape
+    _check(dspdll.dsp_synth_fill(C.c_void_p(tensor.data_ptr()), tensor.stride(0), nch, n, seed, chan0, n0,
+                                 _stream_ptr(stream)), "dsp_synth_fill")
+    return tensor

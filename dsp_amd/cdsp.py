@@ -1,0 +1,131 @@
+"""ctypes binding of libdsp.so.
+
+Mirrors the reference's python/cdsp.py: the same module-level names (`dspdll`,
+`byref_`, `RTFilter_`, `FilterBank_`, `IIRFilterBank_`, `RTFIRFilter_`,
+`RTIIRFilter_`, `i_RTFilter__d`, `v_RTFilter_`), the same Structure layouts
+(cdsp.py:23-52) and the same prototypes (cdsp.py:56-74), so code written
+against the reference binding runs unchanged.  Two things differ on purpose:
+
+* the loader resolves an absolute path (the reference's `cdll.LoadLibrary
+  ('dsp.so')` after editing PATH cannot work on Linux);
+* the additive RTFilterBank_* / dsp_pool_* prototypes of
+  include/RTFilterBank.h are declared as well.
+
+The library is REQUIRED: there is no Python or CPU re-implementation behind
+this module; if lib/libdsp.so is missing the import fails.
+"""
+import ctypes as _C
+import os as _os
+from ctypes import (CFUNCTYPE, POINTER, Structure, byref, c_double, c_int, c_int32, c_size_t,
+                    c_uint, c_uint64, c_void_p, c_char_p)
+
+_LIBDIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib")
+LIBRARY_PATH = _os.environ.get("DSP_AMD_LIBRARY", _os.path.join(_LIBDIR, "libdsp.so"))
+
+if not _os.path.exists(LIBRARY_PATH):
+    raise ImportError(
+        "dsp_amd: %s not found. Build it with `make -C dsp_amd/csrc` "
+        "(or __graft_entry__.build()); there is no fallback implementation." % LIBRARY_PATH)
+
+dspdll = _C.CDLL(LIBRARY_PATH)
+
+
+def byref_(obj, offset=0):
+    """byref that lets None through (python/cdsp.py:17-21)."""
+    return byref(obj, offset) if obj is not None else None
+
+
+class RTFilter_(Structure):
+    pass
+
+
+i_RTFilter__d = CFUNCTYPE(c_int, POINTER(RTFilter_), c_double)
+v_RTFilter_ = CFUNCTYPE(None, POINTER(RTFilter_))
+
+RTFilter_._fields_ = [("update", i_RTFilter__d),
+                      ("initialize", i_RTFilter__d),
+                      ("del", v_RTFilter_),
+                      ("filtered_value", c_double),
+                      ("flags", c_uint),
+                      ("initialized", c_int)]
+
+
+class FilterBank_(Structure):
+    _fields_ = [("b", POINTER(c_double)), ("nb", c_size_t)]
+
+
+class IIRFilterBank_(Structure):
+    _fields_ = [("fb", FilterBank_), ("na", c_size_t)]
+
+
+class RTFIRFilter_(Structure):
+    # the reference names this member `ifb` too (cdsp.py:44-47); same offset as C's `fb`
+    _fields_ = [("rtf", RTFilter_), ("ifb", FilterBank_), ("state", POINTER(c_double))]
+
+
+class RTIIRFilter_(Structure):
+    _fields_ = [("rtf", RTFilter_), ("ifb", IIRFilterBank_), ("state", POINTER(c_double))]
+
+
+class RTFilterDesign_(Structure):
+    """include/RTFilterBank.h: RTFilterDesign."""
+    _fields_ = [("kind", c_int), ("nb", c_size_t), ("na", c_size_t),
+                ("b", POINTER(c_double)), ("a", POINTER(c_double))]
+
+
+_dp = POINTER(c_double)
+_cb = POINTER(i_RTFilter__d)   # the reference declares callbacks as pointer-to-function-pointer
+
+
+def _proto(name, restype, argtypes):
+    fn = getattr(dspdll, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+# ---- prototypes of python/cdsp.py:56-74 ------------------------------------------------------
+_proto("RTFilter_update", c_double, [POINTER(RTFilter_), c_double])
+_proto("RTFilter_updaten", c_int, [_dp, POINTER(RTFilter_), _dp, c_size_t])
+_proto("RTIIRFilter_init", None, [POINTER(RTIIRFilter_), _dp, _dp, c_size_t, c_size_t, c_uint, _cb])
+_proto("RTFIRFilter_init", None, [POINTER(RTFIRFilter_), _dp, _dp, c_size_t, c_uint, _cb])
+_proto("moving_average", c_int, [POINTER(RTFIRFilter_), c_size_t, _cb])
+
+# ---- the rest of include/RTFilter.h that Python callers use ---------------------------------
+_proto("RTFilter_reset", None, [POINTER(RTFilter_)])
+_proto("RTIIRFilter_print", None, [POINTER(RTIIRFilter_)])
+_proto("RTFIRFilter_print", None, [POINTER(RTFIRFilter_)])
+
+# ---- include/RTFilterBank.h -------------------------------------------------------------------
+RTFB_OK, RTFB_EINVAL, RTFB_ESIZE, RTFB_EUNSUPPORTED, RTFB_EDEVICE, RTFB_ENOMEM = range(6)
+RTFB_KIND_IIR, RTFB_KIND_FIR, RTFB_KIND_FIR_PARTIAL = 0, 1, 2
+RTFB_MODE_AUTO, RTFB_MODE_SEQUENTIAL, RTFB_MODE_SCAN = 0, 1, 2
+
+_proto("RTFilterBank_from_filters", c_int, [POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int])
+_proto("RTFilterBank_from_designs", c_int,
+       [POINTER(c_void_p), POINTER(RTFilterDesign_), c_size_t, POINTER(c_int32), c_size_t, c_int])
+_proto("RTFilterBank_destroy", None, [c_void_p])
+_proto("RTFilterBank_channels", c_size_t, [c_void_p])
+_proto("RTFilterBank_set_mode", c_int, [c_void_p, c_int])
+_proto("RTFilterBank_updaten", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
+_proto("RTFilterBank_reset", c_int, [c_void_p, c_void_p])
+_proto("RTFilterBank_sync_to_host", c_int, [c_void_p, c_void_p])
+_proto("RTFilterBank_state_ld", c_size_t, [c_void_p])
+_proto("RTFilterBank_get_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
+_proto("RTFilterBank_set_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
+_proto("RTFilterBank_last_error", c_char_p, [])
+_proto("dsp_pool_alloc", c_int, [POINTER(c_void_p), c_size_t, c_int])
+_proto("dsp_pool_free", c_int, [c_void_p])
+_proto("dsp_pool_trim", c_int, [c_int])
+_proto("dsp_pool_bytes_in_use", c_size_t, [c_int])
+_proto("dsp_pool_bytes_cached", c_size_t, [c_int])
+_proto("dsp_synth_fill", c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_uint64, c_uint64, c_uint64, c_void_p])
+_proto("dsp_device_count", c_int, [])
+_proto("dsp_memcpy_h2d", c_int, [c_void_p, c_void_p, c_size_t, c_int])
+_proto("dsp_memcpy_d2h", c_int, [c_void_p, c_void_p, c_size_t, c_int])
+_proto("dsp_stream_synchronize", c_int, [c_void_p, c_int])
+
+
+def fn_address(name):
+    """Address of an exported function (for pointer-identity checks and struct fields)."""
+    return _C.cast(getattr(dspdll, name), c_void_p).value

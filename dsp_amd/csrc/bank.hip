@@ -1,0 +1,760 @@
+/*
+ * bank.hip -- host side of the MI355X path: the RTFilterBank object (the
+ * block-streaming state manager), the device memory pool, and the C-ABI entry
+ * points of include/RTFilterBank.h.
+ *
+ * A bank owns, in HBM, everything RTFilter_updaten touches per channel
+ * (ref: include/RTFilter.h:30-59): the coefficient tables (deduplicated into
+ * "designs"), the state vectors, filtered_value and initialized.  Samples are
+ * never copied by this layer: callers hand device pointers, kernels read each
+ * input once and write each output once.
+ *
+ * There is no CPU execution path in this file: if HIP or a gfx950 device is
+ * missing every entry point fails with RTFB_EDEVICE.
+ */
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "RTFilterBank.h"
+#include "dsp_internal.h"
+
+namespace {
+
+using namespace dsp;
+
+thread_local std::string t_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    t_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    return fail(RTFB_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);     \
+    } while (0)
+
+/* Make `device` current for the scope, restore the caller's device after
+ * (the caller may be a framework that tracks its own current device). */
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int check_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(RTFB_EDEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(RTFB_EINVAL, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTFB_EDEVICE, std::string("device is ") + prop.gcnArchName +
+                                      "; this library carries gfx950 (MI355X) code only");
+    return RTFB_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* device memory pool: size-bucketed cache over hipMalloc                     */
+
+struct Pool {
+    std::mutex mu;
+    struct Block { size_t bytes; int device; };
+    std::unordered_map<void *, Block> live;                  /* handed out */
+    std::map<std::pair<int, size_t>, std::vector<void *>> cache;   /* (device, bytes) -> free */
+    std::unordered_map<int, size_t> in_use, cached;
+
+    static size_t bucket(size_t bytes)
+    {
+        if (bytes == 0) bytes = 1;
+        if (bytes <= (1u << 20)) {               /* up to 1 MiB: next power of two, >= 256 B */
+            size_t b = 256;
+            while (b < bytes) b <<= 1;
+            return b;
+        }
+        const size_t g = size_t(2) << 20;        /* above: 2 MiB granules */
+        return (bytes + g - 1) / g * g;
+    }
+};
+
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+
+int pool_alloc(void **out, size_t bytes, int device)
+{
+    if (!out) return fail(RTFB_EINVAL, "dsp_pool_alloc: NULL result pointer");
+    Pool &p = pool();
+    const size_t b = Pool::bucket(bytes);
+    {
+        std::lock_guard<std::mutex> lk(p.mu);
+        auto it = p.cache.find({device, b});
+        if (it != p.cache.end() && !it->second.empty()) {
+            void *ptr = it->second.back();
+            it->second.pop_back();
+            p.cached[device] -= b;
+            p.in_use[device] += b;
+            p.live[ptr] = {b, device};
+            *out = ptr;
+            return RTFB_OK;
+        }
+    }
+    DeviceScope ds(device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    void *ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, b);
+    if (e == hipErrorOutOfMemory) {              /* give cached blocks back and retry once */
+        (void)hipGetLastError();
+        dsp_pool_trim(device);
+        e = hipMalloc(&ptr, b);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? RTFB_ENOMEM : RTFB_EDEVICE,
+                    std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.live[ptr] = {b, device};
+    p.in_use[device] += b;
+    *out = ptr;
+    return RTFB_OK;
+}
+
+int pool_free(void *ptr)
+{
+    if (!ptr) return RTFB_OK;
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.live.find(ptr);
+    if (it == p.live.end()) return fail(RTFB_EINVAL, "dsp_pool_free: pointer not from this pool");
+    const Pool::Block blk = it->second;
+    p.live.erase(it);
+    p.in_use[blk.device] -= blk.bytes;
+    p.cached[blk.device] += blk.bytes;
+    p.cache[{blk.device, blk.bytes}].push_back(ptr);
+    return RTFB_OK;
+}
+
+/* typed helper: pooled device array filled from a host vector */
+template <typename T>
+int upload(T **dev, const std::vector<T> &host, int device)
+{
+    *dev = nullptr;
+    if (host.empty()) return RTFB_OK;
+    void *p = nullptr;
+    int rc = pool_alloc(&p, host.size() * sizeof(T), device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T *>(p);
+    return RTFB_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* bank                                                                       */
+
+struct Design {
+    int kind;
+    int nb, na;
+    std::vector<double> b, a;
+    int coef_off = 0;
+    int pow_off = 0;
+    int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
+    bool fast_iir() const
+    {
+        return kind == RTFB_KIND_IIR && nb == na && nb >= 2 && nb - 1 <= kMaxFastOrder;
+    }
+};
+
+enum GroupClass { kIirFast = 0, kIirGeneric = 1 };
+
+struct Group {
+    GroupClass cls;
+    int order = 0;                      /* kIirFast: N */
+    std::vector<int32_t> chans;         /* global channel ids, ascending */
+    int state_ld = 1;
+    /* device */
+    int32_t *d_chan = nullptr;
+    int32_t *d_design = nullptr;
+    double *d_state = nullptr;
+    double *d_fval = nullptr;
+    int32_t *d_init = nullptr;
+    bool contiguous = false;
+};
+
+}  // namespace
+
+struct RTFilterBank {
+    int device = 0;
+    size_t nch = 0;
+    int mode = RTFB_MODE_AUTO;
+    std::vector<Design> designs;
+    std::vector<int32_t> design_of;     /* per channel */
+    std::vector<Group> groups;
+    std::vector<RTFilter *> host_filters;   /* from_filters only */
+    size_t state_ld = 1;                /* uniform ld of the get/set_state API */
+    /* device tables shared by all groups */
+    int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_nb = nullptr, *d_na = nullptr,
+            *d_kind = nullptr;
+    double *d_coefs = nullptr, *d_pows = nullptr;
+};
+
+namespace {
+
+/* A^(T * 2^k), k = 0..5, for the homogeneous recurrence s' = A s of
+ * RTIIRFilter_update with x = 0 (ref: src/RTFilter.c:417-433):
+ *   y = s0 / a0 ;  s_i' = s_{i+1} - a_{i+1} * y   =>  A = U - (a_{1..N}/a0) e0^T.
+ * Computed in long double, stored as doubles, row-major. */
+void scan_powers(const Design &d, int T, std::vector<double> &out)
+{
+    const int N = d.nb - 1;
+    typedef std::vector<long double> Mat;
+    auto mul = [N](const Mat &p, const Mat &q) {
+        Mat r((size_t)N * N, 0.0L);
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < N; ++k) {
+                const long double pik = p[(size_t)i * N + k];
+                if (pik == 0.0L) continue;
+                for (int j = 0; j < N; ++j) r[(size_t)i * N + j] += pik * q[(size_t)k * N + j];
+            }
+        return r;
+    };
+    Mat A((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i) {
+        A[(size_t)i * N] = -(long double)d.a[i + 1] / (long double)d.a[0];
+        if (i + 1 < N) A[(size_t)i * N + i + 1] += 1.0L;
+    }
+    Mat P = A;                                  /* A^1 -> A^T by squaring (T is a power of two) */
+    for (int t = 1; t < T; t <<= 1) P = mul(P, P);
+    for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+        for (size_t e = 0; e < P.size(); ++e) out.push_back((double)P[e]);
+        P = mul(P, P);
+    }
+}
+
+void free_bank_device(RTFilterBank *b)
+{
+    for (Group &g : b->groups) {
+        pool_free(g.d_chan);
+        pool_free(g.d_design);
+        pool_free(g.d_state);
+        pool_free(g.d_fval);
+        pool_free(g.d_init);
+    }
+    pool_free(b->d_coef_off);
+    pool_free(b->d_pow_off);
+    pool_free(b->d_nb);
+    pool_free(b->d_na);
+    pool_free(b->d_kind);
+    pool_free(b->d_coefs);
+    pool_free(b->d_pows);
+}
+
+/* Common tail of both constructors: designs + design_of are filled in;
+ * init_state (nch x state_ld, may be empty = zeros), init_fval, init_init
+ * give the starting per-channel fields. */
+int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
+                const std::vector<double> &init_fval, const std::vector<int32_t> &init_init)
+{
+    const int device = bk->device;
+    DeviceScope ds(device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+
+    /* design tables */
+    std::vector<int32_t> coef_off, pow_off, nb, na, kind;
+    std::vector<double> coefs, pows;
+    size_t ld = 1;
+    for (Design &d : bk->designs) {
+        d.coef_off = (int)coefs.size();
+        coefs.insert(coefs.end(), d.b.begin(), d.b.end());
+        coefs.insert(coefs.end(), d.a.begin(), d.a.end());
+        d.pow_off = (int)pows.size();
+        if (d.fast_iir()) scan_powers(d, kScanT, pows);
+        coef_off.push_back(d.coef_off);
+        pow_off.push_back(d.pow_off);
+        nb.push_back(d.nb);
+        na.push_back(d.na);
+        kind.push_back(d.kind);
+        ld = std::max(ld, (size_t)d.state_slots());
+    }
+    bk->state_ld = ld;
+
+    /* groups */
+    std::map<std::pair<int, int>, size_t> index;
+    for (size_t c = 0; c < bk->nch; ++c) {
+        const Design &d = bk->designs[bk->design_of[c]];
+        std::pair<int, int> key;
+        if (d.kind != RTFB_KIND_IIR)
+            return fail(RTFB_EUNSUPPORTED, "FIR channels are not built into this library yet");
+        if (d.fast_iir()) key = {kIirFast, d.nb - 1};
+        else key = {kIirGeneric, 0};
+        auto it = index.find(key);
+        if (it == index.end()) {
+            Group g;
+            g.cls = (GroupClass)key.first;
+            g.order = key.second;
+            it = index.emplace(key, bk->groups.size()).first;
+            bk->groups.push_back(g);
+        }
+        Group &g = bk->groups[it->second];
+        g.chans.push_back((int32_t)c);
+        g.state_ld = std::max(g.state_ld, d.state_slots());
+    }
+
+    int rc;
+    if ((rc = upload(&bk->d_coef_off, coef_off, device))) return rc;
+    if ((rc = upload(&bk->d_pow_off, pow_off, device))) return rc;
+    if ((rc = upload(&bk->d_nb, nb, device))) return rc;
+    if ((rc = upload(&bk->d_na, na, device))) return rc;
+    if ((rc = upload(&bk->d_kind, kind, device))) return rc;
+    if ((rc = upload(&bk->d_coefs, coefs, device))) return rc;
+    if (pows.empty()) pows.push_back(0.0);
+    if ((rc = upload(&bk->d_pows, pows, device))) return rc;
+
+    for (Group &g : bk->groups) {
+        const size_t cnt = g.chans.size();
+        g.contiguous = (size_t)(g.chans.back() - g.chans.front()) + 1 == cnt;
+        std::vector<int32_t> dsn(cnt), ini(cnt);
+        std::vector<double> st(cnt * (size_t)g.state_ld, 0.0), fv(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            const size_t c = (size_t)g.chans[i];
+            dsn[i] = bk->design_of[c];
+            fv[i] = init_fval.empty() ? 0.0 : init_fval[c];
+            ini[i] = init_init.empty() ? FILTER_RESET : init_init[c];
+            if (!init_state.empty()) {
+                const int slots = bk->designs[dsn[i]].state_slots();
+                for (int k = 0; k < slots; ++k) st[i * g.state_ld + k] = init_state[c * ld + k];
+            }
+        }
+        if (!g.contiguous && (rc = upload(&g.d_chan, g.chans, device))) return rc;
+        if ((rc = upload(&g.d_design, dsn, device))) return rc;
+        if ((rc = upload(&g.d_state, st, device))) return rc;
+        if ((rc = upload(&g.d_fval, fv, device))) return rc;
+        if ((rc = upload(&g.d_init, ini, device))) return rc;
+    }
+    return RTFB_OK;
+}
+
+GroupView view_of(const RTFilterBank *bk, const Group &g)
+{
+    GroupView v;
+    v.chan = g.contiguous ? nullptr : g.d_chan;
+    v.chan0 = g.chans.front();
+    v.count = (int32_t)g.chans.size();
+    v.design = g.d_design;
+    v.state = g.d_state;
+    v.state_ld = g.state_ld;
+    v.fval = g.d_fval;
+    v.init = g.d_init;
+    v.coef_off = bk->d_coef_off;
+    v.pow_off = bk->d_pow_off;
+    v.nb = bk->d_nb;
+    v.na = bk->d_na;
+    v.kind = bk->d_kind;
+    v.coefs = bk->d_coefs;
+    v.pows = bk->d_pows;
+    return v;
+}
+
+/* Below this many channels in a group the sequential (lane = channel) kernel
+ * cannot fill 256 CUs and the time-parallel scan kernel is used instead. */
+constexpr size_t kAutoSeqMinChannels = 65536;
+
+int validate_design(const RTFilterDesign &d)
+{
+    if (d.kind != RTFB_KIND_IIR && d.kind != RTFB_KIND_FIR && d.kind != RTFB_KIND_FIR_PARTIAL)
+        return fail(RTFB_EINVAL, "design.kind is not an RTFB_KIND_* value");
+    if (!d.b || d.nb == 0) return fail(RTFB_EINVAL, "design needs at least one b tap");
+    if (d.kind == RTFB_KIND_IIR) {
+        if (!d.a || d.na == 0) return fail(RTFB_EINVAL, "IIR design needs at least one a tap");
+        if (d.nb > (size_t)kMaxGenericTaps || d.na > (size_t)kMaxGenericTaps)
+            return fail(RTFB_ESIZE, "IIR design exceeds 64 taps");
+    }
+    return RTFB_OK;
+}
+
+}  // namespace
+
+/* ======================================================================== */
+/* C ABI                                                                      */
+
+extern "C" {
+
+const char *RTFilterBank_last_error(void) { return t_last_error.c_str(); }
+
+int dsp_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+int dsp_pool_alloc(void **dev_ptr, size_t bytes, int device) { return pool_alloc(dev_ptr, bytes, device); }
+int dsp_pool_free(void *dev_ptr) { return pool_free(dev_ptr); }
+
+int dsp_pool_trim(int device)
+{
+    Pool &p = pool();
+    std::vector<void *> victims;
+    {
+        std::lock_guard<std::mutex> lk(p.mu);
+        for (auto &kv : p.cache) {
+            if (kv.first.first != device) continue;
+            for (void *ptr : kv.second) victims.push_back(ptr);
+            p.cached[device] -= kv.first.second * kv.second.size();
+            kv.second.clear();
+        }
+    }
+    DeviceScope ds(device);
+    for (void *ptr : victims) (void)hipFree(ptr);
+    return RTFB_OK;
+}
+
+size_t dsp_pool_bytes_in_use(int device)
+{
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    return p.in_use[device];
+}
+
+size_t dsp_pool_bytes_cached(int device)
+{
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    return p.cached[device];
+}
+
+int dsp_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device)
+{
+    DeviceScope ds(device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return RTFB_OK;
+}
+
+int dsp_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device)
+{
+    DeviceScope ds(device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return RTFB_OK;
+}
+
+int dsp_stream_synchronize(void *hip_stream, int device)
+{
+    DeviceScope ds(device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int dsp_synth_fill(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed, uint64_t chan0,
+                   uint64_t n0, void *hip_stream)
+{
+    if (!dst && nch * n) return fail(RTFB_EINVAL, "dsp_synth_fill: NULL destination");
+    if (ld < n) return fail(RTFB_EINVAL, "dsp_synth_fill: ld < n");
+    HIP_TRY(launch_synth(dst, ld, nch, n, seed, chan0, n0, static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *designs, size_t ndesign,
+                              const int32_t *design_of_channel, size_t nch, int device)
+{
+    if (!bank || !designs || !design_of_channel || !ndesign || !nch)
+        return fail(RTFB_EINVAL, "RTFilterBank_from_designs: NULL or empty argument");
+    *bank = nullptr;
+    if (nch > (size_t)INT32_MAX) return fail(RTFB_ESIZE, "too many channels");
+    int rc = check_device(device);
+    if (rc) return rc;
+    RTFilterBank *bk = new RTFilterBank;
+    bk->device = device;
+    bk->nch = nch;
+    for (size_t i = 0; i < ndesign; ++i) {
+        if ((rc = validate_design(designs[i]))) { delete bk; return rc; }
+        Design d;
+        d.kind = designs[i].kind;
+        d.nb = (int)designs[i].nb;
+        d.na = d.kind == RTFB_KIND_IIR ? (int)designs[i].na : 0;
+        d.b.assign(designs[i].b, designs[i].b + d.nb);
+        if (d.na) d.a.assign(designs[i].a, designs[i].a + d.na);
+        bk->designs.push_back(std::move(d));
+    }
+    bk->design_of.assign(design_of_channel, design_of_channel + nch);
+    for (int32_t d : bk->design_of)
+        if (d < 0 || (size_t)d >= ndesign) {
+            delete bk;
+            return fail(RTFB_EINVAL, "design_of_channel entry out of range");
+        }
+    rc = finish_bank(bk, {}, {}, {});
+    if (rc) {
+        free_bank_device(bk);
+        delete bk;
+        return rc;
+    }
+    *bank = bk;
+    return RTFB_OK;
+}
+
+int RTFilterBank_from_filters(RTFilterBank **bank, RTFilter *const *filters, size_t nch, int device)
+{
+    if (!bank || !filters || !nch)
+        return fail(RTFB_EINVAL, "RTFilterBank_from_filters: NULL or empty argument");
+    *bank = nullptr;
+    if (nch > (size_t)INT32_MAX) return fail(RTFB_ESIZE, "too many channels");
+    int rc = check_device(device);
+    if (rc) return rc;
+
+    RTFilterBank *bk = new RTFilterBank;
+    bk->device = device;
+    bk->nch = nch;
+    bk->design_of.resize(nch);
+    bk->host_filters.assign(filters, filters + nch);
+    std::map<std::string, int> seen;            /* coefficient bytes -> design index */
+    std::vector<const double *> st_ptr(nch);
+    size_t ld = 1;
+    for (size_t c = 0; c < nch; ++c) {
+        RTFilter *f = filters[c];
+        if (!f) { delete bk; return fail(RTFB_EINVAL, "NULL filter in array"); }
+        RTFilterDesign rd;
+        std::memset(&rd, 0, sizeof rd);
+        /* acceleration rule: callbacks must be the library's own, by pointer identity */
+        if (f->update == RTIIRFilter_update && f->initialize == RTIIRFilter_stable_init) {
+            RTIIRFilter *q = reinterpret_cast<RTIIRFilter *>(f);
+            rd.kind = RTFB_KIND_IIR;
+            rd.nb = q->ifb.fb.nb;
+            rd.na = q->ifb.na;
+            rd.b = q->ifb.fb.b;
+            rd.a = q->ifb.fb.b + q->ifb.fb.nb;
+            st_ptr[c] = q->state;
+        } else if (f->update == RTFIRFilter_update &&
+                   (f->initialize == RTFIRFilter_stable_init ||
+                    f->initialize == RTFIRFilter_partial_init)) {
+            RTFIRFilter *q = reinterpret_cast<RTFIRFilter *>(f);
+            rd.kind = f->initialize == RTFIRFilter_partial_init ? RTFB_KIND_FIR_PARTIAL : RTFB_KIND_FIR;
+            rd.nb = q->fb.nb;
+            rd.b = q->fb.b;
+            st_ptr[c] = q->state;
+        } else {
+            delete bk;
+            return fail(RTFB_EUNSUPPORTED,
+                        "filter carries update/initialize callbacks that are not this library's");
+        }
+        if ((rc = validate_design(rd)) || !st_ptr[c]) {
+            delete bk;
+            return rc ? rc : fail(RTFB_EINVAL, "filter has no state buffer");
+        }
+        std::string key(reinterpret_cast<const char *>(&rd.kind), sizeof rd.kind);
+        key.append(reinterpret_cast<const char *>(&rd.nb), sizeof rd.nb);
+        key.append(reinterpret_cast<const char *>(&rd.na), sizeof rd.na);
+        key.append(reinterpret_cast<const char *>(rd.b), rd.nb * sizeof(double));
+        if (rd.na) key.append(reinterpret_cast<const char *>(rd.a), rd.na * sizeof(double));
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            Design d;
+            d.kind = rd.kind;
+            d.nb = (int)rd.nb;
+            d.na = (int)rd.na;
+            d.b.assign(rd.b, rd.b + rd.nb);
+            if (rd.na) d.a.assign(rd.a, rd.a + rd.na);
+            it = seen.emplace(key, (int)bk->designs.size()).first;
+            bk->designs.push_back(std::move(d));
+        }
+        bk->design_of[c] = it->second;
+        ld = std::max(ld, (size_t)bk->designs[it->second].state_slots());
+    }
+    std::vector<double> st(nch * ld, 0.0), fv(nch);
+    std::vector<int32_t> ini(nch);
+    for (size_t c = 0; c < nch; ++c) {
+        const int slots = bk->designs[bk->design_of[c]].state_slots();
+        std::memcpy(&st[c * ld], st_ptr[c], slots * sizeof(double));
+        fv[c] = filters[c]->filtered_value;
+        ini[c] = filters[c]->initialized;
+    }
+    rc = finish_bank(bk, st, fv, ini);
+    if (rc) {
+        free_bank_device(bk);
+        delete bk;
+        return rc;
+    }
+    *bank = bk;
+    return RTFB_OK;
+}
+
+void RTFilterBank_destroy(RTFilterBank *bank)
+{
+    if (!bank) return;
+    {
+        DeviceScope ds(bank->device);
+        (void)hipDeviceSynchronize();
+    }
+    free_bank_device(bank);
+    delete bank;
+}
+
+size_t RTFilterBank_channels(const RTFilterBank *bank) { return bank ? bank->nch : 0; }
+size_t RTFilterBank_state_ld(const RTFilterBank *bank) { return bank ? bank->state_ld : 0; }
+
+int RTFilterBank_set_mode(RTFilterBank *bank, int mode)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    if (mode != RTFB_MODE_AUTO && mode != RTFB_MODE_SEQUENTIAL && mode != RTFB_MODE_SCAN)
+        return fail(RTFB_EINVAL, "mode is not an RTFB_MODE_* value");
+    bank->mode = mode;
+    return RTFB_OK;
+}
+
+int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
+                         size_t ld_in, size_t n, void *hip_stream)
+{
+    if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten: NULL argument");
+    if (n == 0) return RTFB_OK;
+    if (bank->nch > 1 && (ld_in < n || ld_out < n))
+        return fail(RTFB_EINVAL, "RTFilterBank_updaten: ld smaller than n");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+
+    BlockIO io;
+    io.out = out;
+    io.ld_out = ld_out;
+    io.in = in;
+    io.ld_in = ld_in;
+    io.n = n;
+    io.aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) &&
+                   ld_in % 2 == 0 && ld_out % 2 == 0;
+
+    for (const Group &g : bank->groups) {
+        const GroupView v = view_of(bank, g);
+        if (g.cls == kIirGeneric) {
+            HIP_TRY(launch_iir_generic(v, io, s));
+            continue;
+        }
+        bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
+                   (bank->mode == RTFB_MODE_AUTO && g.chans.size() >= kAutoSeqMinChannels);
+        if (!seq && !iir_scan_supported(g.order)) seq = true;
+        if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
+        else HIP_TRY(launch_iir_scan(g.order, v, io, s));
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    for (const Group &g : bank->groups)
+        HIP_TRY(launch_reset(view_of(bank, g), static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int RTFilterBank_get_state(RTFilterBank *bank, double *state, double *fval, int32_t *init,
+                           void *hip_stream)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    const size_t ld = bank->state_ld;
+    for (const Group &g : bank->groups) {
+        const size_t cnt = g.chans.size();
+        std::vector<double> st(cnt * (size_t)g.state_ld), fv(cnt);
+        std::vector<int32_t> ini(cnt);
+        HIP_TRY(hipMemcpy(st.data(), g.d_state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(fv.data(), g.d_fval, cnt * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ini.data(), g.d_init, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; ++i) {
+            const size_t c = (size_t)g.chans[i];
+            if (state) {
+                for (size_t k = 0; k < ld; ++k)
+                    state[c * ld + k] = k < (size_t)g.state_ld ? st[i * g.state_ld + k] : 0.0;
+            }
+            if (fval) fval[c] = fv[i];
+            if (init) init[c] = ini[i];
+        }
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBank_set_state(RTFilterBank *bank, const double *state, const double *fval,
+                           const int32_t *init, void *hip_stream)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    const size_t ld = bank->state_ld;
+    for (const Group &g : bank->groups) {
+        const size_t cnt = g.chans.size();
+        if (state) {
+            std::vector<double> st(cnt * (size_t)g.state_ld);
+            for (size_t i = 0; i < cnt; ++i)
+                for (int k = 0; k < g.state_ld; ++k)
+                    st[i * g.state_ld + k] = state[(size_t)g.chans[i] * ld + k];
+            HIP_TRY(hipMemcpy(g.d_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (fval) {
+            std::vector<double> fv(cnt);
+            for (size_t i = 0; i < cnt; ++i) fv[i] = fval[g.chans[i]];
+            HIP_TRY(hipMemcpy(g.d_fval, fv.data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (init) {
+            std::vector<int32_t> ini(cnt);
+            for (size_t i = 0; i < cnt; ++i) ini[i] = init[g.chans[i]];
+            HIP_TRY(hipMemcpy(g.d_init, ini.data(), cnt * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    if (bank->host_filters.empty())
+        return fail(RTFB_EINVAL, "bank was not built from host filters");
+    const size_t ld = bank->state_ld;
+    std::vector<double> st(bank->nch * ld), fv(bank->nch);
+    std::vector<int32_t> ini(bank->nch);
+    int rc = RTFilterBank_get_state(bank, st.data(), fv.data(), ini.data(), hip_stream);
+    if (rc) return rc;
+    for (size_t c = 0; c < bank->nch; ++c) {
+        RTFilter *f = bank->host_filters[c];
+        const Design &d = bank->designs[bank->design_of[c]];
+        double *dst = d.kind == RTFB_KIND_IIR ? reinterpret_cast<RTIIRFilter *>(f)->state
+                                              : reinterpret_cast<RTFIRFilter *>(f)->state;
+        std::memcpy(dst, &st[c * ld], d.state_slots() * sizeof(double));
+        f->filtered_value = fv[c];
+        f->initialized = ini[c];
+    }
+    return RTFB_OK;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,63 @@
+/* dsp_internal.h -- shared between bank.hip (host-side bank manager) and
+ * kernels.hip (gfx950 kernels + their launchers).  Not installed. */
+#ifndef DSP_INTERNAL_H
+#define DSP_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dsp {
+
+constexpr int kWave = 64;            /* CDNA wavefront */
+constexpr int kMaxFastOrder = 16;    /* IIR orders with unrolled kernels (na == nb == N+1) */
+constexpr int kMaxGenericTaps = 64;  /* na, nb limit of the generic IIR kernel */
+constexpr int kScanLevels = 6;       /* log2(kWave): Kogge-Stone steps across a wavefront */
+
+/* Sub-chunk (samples per lane per tile) of each kernel family.  A tile is
+ * 64 rows x T doubles staged through LDS with one 16-byte pad per row. */
+constexpr int kSeqT = 32;            /* sequential kernel: rows are channels          */
+constexpr int kScanT = 64;           /* scan kernel: rows are consecutive time chunks */
+
+/* One launch group: channels of the bank that share a kernel. All pointers are
+ * device pointers; arrays are indexed by the group-local channel index g. */
+struct GroupView {
+    const int32_t *chan;      /* global channel id per g, or nullptr: channel = chan0 + g */
+    int32_t        chan0;
+    int32_t        count;
+    const int32_t *design;    /* design index per g                                       */
+    double        *state;     /* count x state_ld                                         */
+    int32_t        state_ld;
+    double        *fval;      /* RTFilter.filtered_value per g                            */
+    int32_t       *init;      /* RTFilter.initialized per g                               */
+    const int32_t *coef_off;  /* per design: offset of b[0] in coefs (a follows b)        */
+    const int32_t *pow_off;   /* per design: offset of the kScanLevels N x N matrices     */
+    const int32_t *nb;        /* per design                                               */
+    const int32_t *na;        /* per design                                               */
+    const int32_t *kind;      /* per design: RTFB_KIND_*                                  */
+    const double  *coefs;
+    const double  *pows;
+};
+
+struct BlockIO {
+    double       *out;
+    size_t        ld_out;
+    const double *in;
+    size_t        ld_in;
+    size_t        n;
+    int           aligned16;  /* in/out/ld allow 16-byte vector access */
+};
+
+/* launchers (kernels.hip).  Each returns the hipError_t of the launch. */
+hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_reset(const GroupView &g, hipStream_t s);
+hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
+                        uint64_t chan0, uint64_t n0, hipStream_t s);
+
+bool iir_scan_supported(int order);
+
+}  // namespace dsp
+
+#endif

@@ -1,0 +1,612 @@
+/*
+ * kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels for the RTFilter
+ * update path.  Wave64 throughout; no other target is supported.
+ *
+ * Built with -ffp-contract=off: every `*` and `+` below is its own IEEE
+ * binary64 rounding, exactly like the reference build (src/make_dll.mak:16).
+ * Where a fused multiply-add is wanted (the zero-state pass and the prefix
+ * combine of the scan kernel, neither of which is on the bit-exact path) it
+ * is written explicitly as __builtin_fma.
+ *
+ * Data movement pattern shared by the kernels: a wavefront owns a TILE of 64
+ * rows x T doubles.  The tile is fetched with coalesced 16-byte loads (lane l
+ * of load i takes piece i*64+l), parked in LDS with a 16-byte pad per row so
+ * that the per-lane row walk (ds_read_b128 at row stride T*8+16) is
+ * bank-conflict free, processed in place (lane r walks row r), and written
+ * back with coalesced 16-byte stores.  HBM sees each sample once in, once out:
+ * 16 B/sample, the algorithmic minimum.
+ */
+#include "dsp_internal.h"
+
+namespace dsp {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+/* Read-only tables (coefficients, matrix powers, design indices) are read
+ * through the constant address space so that wave-uniform loads become scalar
+ * loads (s_load_*) into SGPRs even though the kernel also stores to global
+ * memory; the bank never aliases its tables with sample buffers. */
+typedef const double __attribute__((address_space(4))) *cdouble_p;
+typedef const int32_t __attribute__((address_space(4))) *cint_p;
+__device__ __forceinline__ cdouble_p as_const(const double *p)
+{
+    return (cdouble_p)(uintptr_t)p;
+}
+__device__ __forceinline__ cint_p as_const(const int32_t *p)
+{
+    return (cint_p)(uintptr_t)p;
+}
+
+template <int T>
+struct Tile {
+    static_assert(T >= 2 && (T & (T - 1)) == 0, "T must be a power of two");
+    static constexpr int kRowBytes = T * 8 + 16;
+    static constexpr int kPiecesPerRow = T / 2;
+    static constexpr int kLoads = T / 2;              /* 16-byte pieces per lane per tile */
+    static constexpr int kBytes = kWave * kRowBytes;
+};
+
+/* ------------------------------------------------------------------------ */
+/* arithmetic leaves                                                         */
+
+/* One RTIIRFilter_update (ref: src/RTFilter.c:396-439) for na == nb == N+1, in
+ * the reference's exact operation order:
+ *   y    = ((x*b0) + s0) / a0
+ *   t    = (0.0 + b[i+1]*x) - a[i+1]*y ;  s[i] = s[i+1] + t      i = 0..N-1
+ * The literal `0.0 +` is kept: it turns a -0.0 product into +0.0 as the
+ * reference's `state_value = 0.0; state_value += ...` does.  x / 1.0 == x
+ * exactly, so the divide is skipped when a0 == 1 (every reference design sets
+ * a0 = 1: src/RTFilter.c:1156,1255,1352). */
+template <int N>
+__device__ __forceinline__ double iir_step_ref(double x, double (&s)[N + 1],
+                                               const double (&b)[N + 1],
+                                               const double (&a)[N + 1])
+{
+    double t = x * b[0];
+    t = t + s[0];
+    double y = t;
+    if (a[0] != 1.0) y = t / a[0];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double u = 0.0 + b[i + 1] * x;
+        u = u - a[i + 1] * y;
+        s[i] = s[i + 1] + u;
+    }
+    return y;
+}
+
+/* Same recurrence with explicit FMAs: used only where the result feeds the
+ * prefix combine (zero-state pass), never for an output sample. */
+template <int N>
+__device__ __forceinline__ void iir_step_fused(double x, double (&s)[N + 1],
+                                               const double (&b)[N + 1],
+                                               const double (&a)[N + 1])
+{
+    double y = __builtin_fma(x, b[0], s[0]);
+    if (a[0] != 1.0) y = y / a[0];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        s[i] = __builtin_fma(-a[i + 1], y, __builtin_fma(b[i + 1], x, s[i + 1]));
+}
+
+/* RTIIRFilter_stable_init (ref: src/RTFilter.c:441-475), na == nb == N+1 >= 2. */
+template <int N>
+__device__ __forceinline__ double iir_seed_ref(double x, double (&s)[N + 1],
+                                               const double (&b)[N + 1],
+                                               const double (&a)[N + 1])
+{
+    double num = 0.0 + b[0];
+    num = num + b[1];
+    double den = 0.0 + a[0];
+    den = den + a[1];
+    const double d = num / den;
+    double run = 0.0;
+    s[N] = 0.0;
+#pragma unroll
+    for (int i = N; i >= 1; --i) {
+        run = run + b[i];
+        run = run - a[i] * d;
+        s[i - 1] = run * x;
+    }
+    return d * x;
+}
+
+__device__ __forceinline__ int group_channel(const GroupView &g, int idx)
+{
+    return g.chan ? g.chan[idx] : g.chan0 + idx;
+}
+
+__device__ __forceinline__ double shfl_up_f64(double v, int delta)
+{
+    return __shfl_up(v, delta, kWave);
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src)
+{
+    return __shfl(v, src, kWave);
+}
+
+/* ------------------------------------------------------------------------ */
+/* K_seq: one lane = one channel, reference order => bit-exact.               */
+/* A wavefront owns 64 channels and walks time in tiles of T samples; state   */
+/* and coefficients stay in registers for the whole block.                    */
+
+template <int N, int T>
+__global__ void __launch_bounds__(kWave)
+iir_seq_kernel(GroupView g, BlockIO io)
+{
+    using TG = Tile<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * kWave;
+    const int gi = g0 + lane;
+    const bool live = gi < g.count;
+    const int gc = live ? gi : g.count - 1;
+    const int chan = group_channel(g, gc);
+
+    double b[N + 1], a[N + 1], s[N + 1];
+    {
+        const double *cf = g.coefs + g.coef_off[g.design[gc]];
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            b[i] = cf[i];
+            a[i] = cf[N + 1 + i];
+        }
+        const double *st = g.state + (size_t)gc * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) s[i] = st[i];
+    }
+    double y = g.fval[gc];
+    int ini = g.init[gc];
+
+    const size_t n = io.n;
+    for (size_t t0 = 0; t0 < n; t0 += T) {
+        const int cnt = (n - t0 < (size_t)T) ? (int)(n - t0) : T;
+
+        /* stage in: piece p = i*64+lane -> row p/(T/2), 16-byte column p%(T/2) */
+#pragma unroll 4
+        for (int i = 0; i < TG::kLoads; ++i) {
+            const int p = i * kWave + lane;
+            const int r = p / TG::kPiecesPerRow;
+            const int q = p % TG::kPiecesPerRow;
+            const int cr = __shfl(chan, r, kWave);
+            const bool row_live = (g0 + r) < g.count;
+            const int k = 2 * q;
+            d2 v = {0.0, 0.0};
+            if (row_live && k < cnt) {
+                const double *src = io.in + (size_t)cr * io.ld_in + t0 + k;
+                if (k + 1 < cnt) {
+                    if (io.aligned16) v = *reinterpret_cast<const d2 *>(src);
+                    else { v.x = src[0]; v.y = src[1]; }
+                } else {
+                    v.x = src[0];
+                }
+            }
+            *reinterpret_cast<d2 *>(smem + r * TG::kRowBytes + q * 16) = v;
+        }
+        __syncthreads();
+
+        /* walk my row in the reference's order */
+        char *row = smem + lane * TG::kRowBytes;
+        for (int k = 0; k < cnt; k += 2) {
+            d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
+            if (ini != 0) { y = iir_seed_ref<N>(xv.x, s, b, a); ini = 0; }
+            else y = iir_step_ref<N>(xv.x, s, b, a);
+            xv.x = y;
+            if (k + 1 < cnt) {
+                y = iir_step_ref<N>(xv.y, s, b, a);
+                xv.y = y;
+            }
+            *reinterpret_cast<d2 *>(row + k * 8) = xv;
+        }
+        __syncthreads();
+
+        /* stage out */
+#pragma unroll 4
+        for (int i = 0; i < TG::kLoads; ++i) {
+            const int p = i * kWave + lane;
+            const int r = p / TG::kPiecesPerRow;
+            const int q = p % TG::kPiecesPerRow;
+            const int cr = __shfl(chan, r, kWave);
+            const bool row_live = (g0 + r) < g.count;
+            const int k = 2 * q;
+            if (row_live && k < cnt) {
+                const d2 v = *reinterpret_cast<const d2 *>(smem + r * TG::kRowBytes + q * 16);
+                double *dst = io.out + (size_t)cr * io.ld_out + t0 + k;
+                if (k + 1 < cnt) {
+                    if (io.aligned16) *reinterpret_cast<d2 *>(dst) = v;
+                    else { dst[0] = v.x; dst[1] = v.y; }
+                } else {
+                    dst[0] = v.x;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (live) {
+        double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) st[i] = s[i];
+        g.fval[gi] = y;
+        g.init[gi] = ini;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* K_scan: one wavefront = one channel; time-parallel inside the wavefront.  */
+/*                                                                            */
+/* A segment is 64*T consecutive samples of the channel; lane j owns samples  */
+/* [jT, (j+1)T).  Per segment:                                                */
+/*   pass 1  every lane runs the recurrence over its T samples from a ZERO    */
+/*           start (lane 0: from the carried state) -> end vector v_j         */
+/*   combine Kogge-Stone prefix over lanes of the affine maps s -> M s + v,   */
+/*           M = A^T (A = companion matrix of the homogeneous recurrence);    */
+/*           step k uses the precomputed power A^(T*2^k): 6 N x N mat-vecs    */
+/*   pass 2  every lane re-runs its T samples from its TRUE start state in    */
+/*           the reference's operation order and writes y in place            */
+/* The carried state of the next segment is lane 63's state after pass 2.     */
+/* x is read from HBM once and y written once; both passes run out of LDS.    */
+/* Pass 2 being the reference's own arithmetic, an output differs from the    */
+/* reference only through the rounding of its lane's start state, which the   */
+/* filter's own decay damps.                                                  */
+
+template <int N, int T, bool kGeneral>
+__device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, bool do_seed,
+                                             const double (&b)[N + 1], const double (&a)[N + 1],
+                                             cdouble_p pw,
+                                             double (&carry)[N + 1], double &ylast)
+{
+    using TG = Tile<T>;
+    char *row = smem + lane * TG::kRowBytes;
+
+    /* samples this lane owns */
+    int cnt = T;
+    int jlast = kWave - 1;
+    if (kGeneral) {
+        cnt = seg_len - lane * T;
+        cnt = cnt < 0 ? 0 : (cnt > T ? T : cnt);
+        jlast = (seg_len - 1) / T;
+    }
+    const bool seed_here = kGeneral && do_seed && lane == 0;
+    const double tail = (kGeneral && do_seed) ? 0.0 : carry[N];   /* s[N]: read, never written */
+
+    /* ---- pass 1 ---- */
+    double v[N + 1];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = (lane == 0) ? carry[i] : 0.0;
+    v[N] = tail;
+    if (kGeneral) {
+        int k = 0;
+        if (seed_here) { (void)iir_seed_ref<N>(*reinterpret_cast<double *>(row), v, b, a); k = 1; }
+        for (; k < cnt; ++k) iir_step_fused<N>(*reinterpret_cast<double *>(row + k * 8), v, b, a);
+    } else {
+#pragma unroll 2
+        for (int k = 0; k < T; k += 2) {
+            const d2 xv = *reinterpret_cast<const d2 *>(row + k * 8);
+            iir_step_fused<N>(xv.x, v, b, a);
+            iir_step_fused<N>(xv.y, v, b, a);
+        }
+    }
+
+    /* ---- prefix combine across lanes: v_j <- end state after lane j ---- */
+#pragma unroll
+    for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+        const int d = 1 << lvl;
+        double u[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double up = shfl_up_f64(v[i], d);
+            u[i] = (lane >= d) ? up : 0.0;
+        }
+        cdouble_p M = pw + lvl * N * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double acc = v[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc = __builtin_fma(M[i * N + j], u[j], acc);
+            v[i] = acc;
+        }
+    }
+
+    /* ---- pass 2: true start state = end state of the lane before ---- */
+    double s[N + 1];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double prev = shfl_up_f64(v[i], 1);
+        s[i] = (lane == 0) ? carry[i] : prev;
+    }
+    s[N] = tail;
+    double y = ylast;
+    if (kGeneral) {
+        int k = 0;
+        if (seed_here) {
+            y = iir_seed_ref<N>(*reinterpret_cast<double *>(row), s, b, a);
+            *reinterpret_cast<double *>(row) = y;
+            k = 1;
+        }
+        for (; k < cnt; ++k) {
+            y = iir_step_ref<N>(*reinterpret_cast<double *>(row + k * 8), s, b, a);
+            *reinterpret_cast<double *>(row + k * 8) = y;
+        }
+    } else {
+#pragma unroll 2
+        for (int k = 0; k < T; k += 2) {
+            d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
+            xv.x = iir_step_ref<N>(xv.x, s, b, a);
+            xv.y = y = iir_step_ref<N>(xv.y, s, b, a);
+            *reinterpret_cast<d2 *>(row + k * 8) = xv;
+        }
+    }
+
+    /* carry out = state of the lane that consumed the segment's last sample */
+#pragma unroll
+    for (int i = 0; i <= N; ++i) carry[i] = shfl_f64(s[i], jlast);
+    ylast = shfl_f64(y, jlast);
+}
+
+template <int N, int T>
+__global__ void __launch_bounds__(kWave)
+iir_scan_kernel(GroupView g, BlockIO io)
+{
+    using TG = Tile<T>;
+    constexpr int kSeg = kWave * T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x;
+    const int gi = blockIdx.x;                       /* one wavefront per channel */
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+
+    double b[N + 1], a[N + 1], carry[N + 1];
+    {
+        cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            b[i] = cf[i];
+            a[i] = cf[N + 1 + i];
+        }
+        const double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) carry[i] = st[i];
+    }
+    cdouble_p pw = as_const(g.pows) + as_const(g.pow_off)[dsn];
+    double ylast = g.fval[gi];
+    bool need_seed = g.init[gi] != 0;
+
+    const size_t n = io.n;
+    const double *src = io.in + (size_t)chan * io.ld_in;
+    double *dst = io.out + (size_t)chan * io.ld_out;
+
+    d2 pre[TG::kLoads];
+    auto fetch = [&](size_t base) {
+        const size_t left = n - base;
+        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
+        if (seg_len == kSeg && io.aligned16) {
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i)
+                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+        } else {
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int e = 2 * (i * kWave + lane);
+                d2 v = {0.0, 0.0};
+                if (e < seg_len) v.x = src[base + e];
+                if (e + 1 < seg_len) v.y = src[base + e + 1];
+                pre[i] = v;
+            }
+        }
+    };
+
+    fetch(0);
+    for (size_t base = 0; base < n; base += kSeg) {
+        const size_t left = n - base;
+        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
+
+        /* park the prefetched segment in LDS (row = lane-chunk, padded) */
+#pragma unroll
+        for (int i = 0; i < TG::kLoads; ++i) {
+            const int p = i * kWave + lane;
+            *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
+                                    (p % TG::kPiecesPerRow) * 16) = pre[i];
+        }
+        __syncthreads();
+        if (base + kSeg < n) fetch(base + kSeg);     /* next segment's loads fly during compute */
+
+        if (seg_len == kSeg && !need_seed)
+            scan_segment<N, T, false>(smem, lane, seg_len, false, b, a, pw, carry, ylast);
+        else
+            scan_segment<N, T, true>(smem, lane, seg_len, need_seed, b, a, pw, carry, ylast);
+        need_seed = false;
+        __syncthreads();
+
+        if (seg_len == kSeg && io.aligned16) {
+#pragma unroll 8
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int p = i * kWave + lane;
+                *reinterpret_cast<d2 *>(dst + base + 2 * p) = *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int p = i * kWave + lane;
+                const int e = 2 * p;
+                const d2 v = *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+                if (e < seg_len) dst[base + e] = v.x;
+                if (e + 1 < seg_len) dst[base + e + 1] = v.y;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (lane == 0) {
+        double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) st[i] = carry[i];
+        g.fval[gi] = ylast;
+        g.init[gi] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Generic IIR (na != nb, or order above the unrolled kernels): one thread   */
+/* per channel straight out of global memory, reference order, bit-exact.     */
+/* Compatibility path for unusual shapes; not a performance kernel.           */
+
+__global__ void __launch_bounds__(kWave)
+iir_generic_kernel(GroupView g, BlockIO io)
+{
+    const int gi = blockIdx.x * kWave + threadIdx.x;
+    if (gi >= g.count) return;
+    const int chan = group_channel(g, gi);
+    const int dsn = g.design[gi];
+    const int nb = g.nb[dsn], na = g.na[dsn];
+    const int order = (nb > na ? nb : na) - 1;
+    const double *b = g.coefs + g.coef_off[dsn];
+    const double *a = b + nb;
+    double *s = g.state + (size_t)gi * g.state_ld;
+    const double *x = io.in + (size_t)chan * io.ld_in;
+    double *out = io.out + (size_t)chan * io.ld_out;
+    double y = g.fval[gi];
+    int ini = g.init[gi];
+    for (size_t k = 0; k < io.n; ++k) {
+        const double xv = x[k];
+        if (ini != 0) {
+            double num = 0.0, den = 0.0;
+            for (int j = 0; j <= 1; ++j) {
+                if (j < nb) num = num + b[j];
+                if (j < na) den = den + a[j];
+            }
+            const double d = num / den;
+            double run = 0.0;
+            s[order] = 0.0;
+            for (int i = order; i >= 1; --i) {
+                if (i < nb) run = run + b[i];
+                if (i < na) run = run - a[i] * d;
+                s[i - 1] = run * xv;
+            }
+            y = d * xv;
+            ini = 0;
+        } else {
+            double t = xv * b[0];
+            t = t + s[0];
+            y = t / a[0];
+            for (int i = 0; i < order; ++i) {
+                double u = 0.0;
+                if (i + 1 < nb) u = u + b[i + 1] * xv;
+                if (i + 1 < na) u = u - a[i + 1] * y;
+                s[i] = s[i + 1] + u;
+            }
+        }
+        out[k] = y;
+    }
+    g.fval[gi] = y;
+    g.init[gi] = ini;
+}
+
+/* RTFilter_reset over a group (ref: src/RTFilter.c:55-58): state untouched. */
+__global__ void reset_kernel(GroupView g)
+{
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < g.count) {
+        g.init[gi] = -1;
+        g.fval[gi] = 0.0;
+    }
+}
+
+/* Synthetic input generator; two samples per thread. */
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_kernel(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
+                             uint64_t chan0, uint64_t n0)
+{
+    const size_t total = nch * n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = idx / n, k = idx % n;
+        const uint64_t h = splitmix64(seed ^ (((chan0 + c) << 32) + (n0 + k)));
+        dst[c * ld + k] = (double)(int64_t)(h >> 11) * 0x1.0p-52 - 1.0;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* launchers                                                                  */
+
+template <int N>
+static hipError_t launch_seq_n(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    const int blocks = (g.count + kWave - 1) / kWave;
+    hipLaunchKernelGGL((iir_seq_kernel<N, kSeqT>), dim3(blocks), dim3(kWave),
+                       Tile<kSeqT>::kBytes, s, g, io);
+    return hipGetLastError();
+}
+
+template <int N>
+static hipError_t launch_scan_n(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    hipLaunchKernelGGL((iir_scan_kernel<N, kScanT>), dim3(g.count), dim3(kWave),
+                       Tile<kScanT>::kBytes, s, g, io);
+    return hipGetLastError();
+}
+
+#define DSP_FOR_EACH_ORDER(X) \
+    X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    switch (order) {
+#define X(N) case N: return launch_seq_n<N>(g, io, s);
+        DSP_FOR_EACH_ORDER(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+bool iir_scan_supported(int order) { return order >= 1 && order <= kMaxFastOrder; }
+
+hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    switch (order) {
+#define X(N) case N: return launch_scan_n<N>(g, io, s);
+        DSP_FOR_EACH_ORDER(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    const int blocks = (g.count + kWave - 1) / kWave;
+    hipLaunchKernelGGL(iir_generic_kernel, dim3(blocks), dim3(kWave), 0, s, g, io);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(const GroupView &g, hipStream_t s)
+{
+    const int blocks = (g.count + 255) / 256;
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
+                        uint64_t chan0, uint64_t n0, hipStream_t s)
+{
+    const size_t total = nch * n;
+    if (!total) return hipSuccess;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, ld, nch, n, seed,
+                       chan0, n0);
+    return hipGetLastError();
+}
+
+}  // namespace dsp

@@ -1,0 +1,140 @@
+"""Python face of libdsp: the callable filter objects of the reference's python/dsp.py.
+
+Behaviour mirrored from python/dsp.py (reference file:line in each docstring):
+  * RTIIRFilter(b, a) / RTFIRFilter(b) own a ctypes coefficient bank and state
+    and a caller-instantiated C struct (dsp.py:15-24, 48-56);
+  * calling one with a number -> RTFilter_update; with a Sequence -> one
+    RTFilter_updaten, list out (None on a non-zero status); with any other
+    iterable -> a lazy per-sample iterator (dsp.py:25-38);
+  * design helpers size the bank like the reference does (dsp.py:79-124).
+
+Known reference bugs are NOT reproduced: chebyshev1/2 pass `ripple` to C,
+moving_average has no undefined `flags`.
+"""
+from collections.abc import Iterable, Sequence
+from ctypes import c_double
+
+from . import cdsp
+from .cdsp import byref_, dspdll
+
+
+class FilterIterator:
+    """Lazy per-sample filtering of an iterator (python/dsp.py:6-13)."""
+
+    def __init__(self, filter, samples):
+        self.filter = filter
+        self.samples = iter(samples)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.filter(next(self.samples))
+
+
+class _RTFilterObject:
+    """Shared call protocol; subclasses provide self._cstruct (first member: RTFilter)."""
+
+    def _rtf(self):
+        return byref_(self._cstruct.rtf)
+
+    def __call__(self, value):
+        if isinstance(value, Sequence):
+            n = len(value)
+            buf_t = c_double * n
+            cin, cout = buf_t(*value), buf_t()
+            status = dspdll.RTFilter_updaten(cout, self._rtf(), cin, n)
+            return None if status else list(cout)
+        if isinstance(value, Iterable):
+            return FilterIterator(self, value)
+        return dspdll.RTFilter_update(self._rtf(), value)
+
+    def reset(self):
+        dspdll.RTFilter_reset(self._rtf())
+
+    def cobj(self):
+        return self._cstruct
+
+    @property
+    def filtered_value(self):
+        return self._cstruct.rtf.filtered_value
+
+    @property
+    def initialized(self):
+        return self._cstruct.rtf.initialized
+
+
+class RTIIRFilter(_RTFilterObject):
+    """python/dsp.py:15-46.  Bank = b then a in one array; state over-sized to na+nb."""
+
+    def __init__(self, b, a, flags=0, initialize=None):
+        self.na, self.nb = len(a), len(b)
+        total = self.na + self.nb
+        self._b = (c_double * total)(*b, *a)
+        self._state = (c_double * total)()
+        self._rtif = self._cstruct = cdsp.RTIIRFilter_()
+        self.initialize = initialize
+        dspdll.RTIIRFilter_init(byref_(self._rtif), self._b, self._state, self.na, self.nb, flags,
+                                byref_(self.initialize))
+        if initialize is None:
+            # RTIIRFilter_init stores the initialize argument verbatim; a NULL would be called
+            # through on the first sample.  Install the library default,
+            # which is what every reference design routine ends up doing (RTFilter.c:1224-1226).
+            self.use_stable_init()
+
+    def use_stable_init(self):
+        self._rtif.rtf.initialize = cdsp.i_RTFilter__d(cdsp.fn_address("RTIIRFilter_stable_init"))
+
+    def print(self):
+        dspdll.RTIIRFilter_print(byref_(self._rtif))
+
+    def b(self):
+        return tuple(self._b[: self._rtif.ifb.fb.nb])
+
+    def a(self):
+        nb = self._rtif.ifb.fb.nb
+        return tuple(self._b[nb: nb + self._rtif.ifb.na])
+
+    def state(self):
+        return tuple(self._state[: max(self._rtif.ifb.na, self._rtif.ifb.fb.nb)])
+
+
+class RTFIRFilter(_RTFilterObject):
+    """python/dsp.py:48-76."""
+
+    def __init__(self, b, flags=0, initialize=None):
+        self.nb = len(b)
+        self._b = (c_double * self.nb)(*b)
+        self._state = (c_double * self.nb)()
+        self._rtff = self._cstruct = cdsp.RTFIRFilter_()
+        self.initialize = initialize
+        dspdll.RTFIRFilter_init(byref_(self._rtff), self._b, self._state, self.nb, flags,
+                                byref_(self.initialize))
+        if initialize is None:
+            self.use_stable_init()
+
+    def use_stable_init(self):
+        self._rtff.rtf.initialize = cdsp.i_RTFilter__d(cdsp.fn_address("RTFIRFilter_stable_init"))
+
+    def use_partial_init(self):
+        self._rtff.rtf.initialize = cdsp.i_RTFilter__d(cdsp.fn_address("RTFIRFilter_partial_init"))
+
+    def print(self):
+        dspdll.RTFIRFilter_print(byref_(self._rtff))
+
+    def b(self):
+        return tuple(self._b[: self._rtff.ifb.nb])
+
+    def state(self):
+        return tuple(self._state[: self._rtff.ifb.nb])
+
+
+def moving_average(window, initialize=None):
+    """python/dsp.py:118-124 (with the undefined `flags` fixed): window equal taps, ramp-in init."""
+    if initialize is not None:
+        initialize = cdsp.i_RTFilter__d(initialize)
+    rtff = RTFIRFilter([0.0] * window, 0, initialize)
+    status = dspdll.moving_average(byref_(rtff.cobj()), window, byref_(initialize))
+    if status:
+        raise ValueError("moving_average: status %d" % status)
+    return rtff

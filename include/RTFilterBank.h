@@ -1,0 +1,133 @@
+/*
+ * RTFilterBank.h -- additive MI355X (gfx950) API of libdsp: many independent
+ * RTFilter channels advanced together on device-resident sample blocks.
+ *
+ * The reference has no multichannel entry point; a caller loops
+ *     RTFilter_updaten(out_c, filter_c, in_c, n)      (ref: include/RTFilter.h:89,
+ *                                                       src/RTFilter.c:111-119)
+ * once per filter.  RTFilterBank_updaten is defined as exactly that loop over
+ * the bank's channels -- same outputs, same end state, same `filtered_value`
+ * and `initialized` per channel -- executed by hand-written HIP kernels, with
+ * the filter state living in HBM between calls so that consecutive blocks
+ * stream (the "block-streaming state manager" of the design).
+ *
+ * Everything here is plain C ABI: opaque handle, raw device pointers, sizes,
+ * int status.  No torch / C++ types cross this boundary.
+ *
+ * Status codes extend the reference's convention (src/RTFilter.c:112-114,
+ * 1217-1223: 0 ok, 1 bad argument, 2 bank/size problem).
+ */
+#ifndef RTFILTERBANK_H
+#define RTFILTERBANK_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "RTFilter.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTFB_OK            0
+#define RTFB_EINVAL        1   /* NULL / malformed argument (reference code 1)              */
+#define RTFB_ESIZE         2   /* a size the bank cannot take (reference code 2)            */
+#define RTFB_EUNSUPPORTED  3   /* filter carries callbacks that are not the library's own   */
+#define RTFB_EDEVICE       4   /* HIP runtime error or no gfx950 device; see last_error     */
+#define RTFB_ENOMEM        5
+
+typedef struct RTFilterBank RTFilterBank;
+
+/* What a channel computes: mirrors the (update, initialize) callback pair a
+ * reference filter carries. */
+#define RTFB_KIND_IIR          0   /* RTIIRFilter_update   + RTIIRFilter_stable_init  */
+#define RTFB_KIND_FIR          1   /* RTFIRFilter_update   + RTFIRFilter_stable_init  */
+#define RTFB_KIND_FIR_PARTIAL  2   /* RTFIRFilter_update   + RTFIRFilter_partial_init */
+
+/* One distinct coefficient set; channels reference designs by index. */
+typedef struct RTFilterDesign {
+    int           kind;   /* RTFB_KIND_*                                   */
+    size_t        nb;     /* taps in b (FIR: the filter length)            */
+    size_t        na;     /* taps in a (IIR only; 0 for FIR)               */
+    const double *b;      /* host pointer, nb doubles                      */
+    const double *a;      /* host pointer, na doubles (IIR)                */
+} RTFilterDesign;
+
+/* Kernel choice for IIR channels. */
+#define RTFB_MODE_AUTO        0   /* sequential when the bank has enough channels, else scan */
+#define RTFB_MODE_SEQUENTIAL  1   /* one lane per channel, reference operation order: bit-exact */
+#define RTFB_MODE_SCAN        2   /* time-parallel chunked state-space scan: <=1e-12 rel-to-peak on
+                                     well-conditioned designs, not bit-exact */
+
+/* Build a bank from host filters.  Each entry must be an RTIIRFilter or
+ * RTFIRFilter whose callbacks are this library's own (pointer identity, the
+ * "acceleration rule"); anything else -> RTFB_EUNSUPPORTED.  Coefficients and
+ * the CURRENT state / filtered_value / initialized are copied to `device`.
+ * The filter pointers are retained for RTFilterBank_sync_to_host and must
+ * outlive the bank. */
+EXPORT int RTFilterBank_from_filters(RTFilterBank **bank, RTFilter *const *filters,
+                                     size_t nch, int device);
+
+/* Build a bank from packed tables: design_of_channel[c] in [0, ndesign).
+ * All channels start in the state RT{IIR,FIR}Filter_init leaves (state zero,
+ * initialized = FILTER_RESET). */
+EXPORT int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *designs,
+                                     size_t ndesign, const int32_t *design_of_channel,
+                                     size_t nch, int device);
+
+EXPORT void   RTFilterBank_destroy(RTFilterBank *bank);
+EXPORT size_t RTFilterBank_channels(const RTFilterBank *bank);
+EXPORT int    RTFilterBank_set_mode(RTFilterBank *bank, int mode);
+
+/* For every channel c: RTFilter_updaten(out + c*ld_out, filter_c, in + c*ld_in, n).
+ * in/out are DEVICE pointers on the bank's device, channel-major, ld_* in
+ * doubles (>= n); in == out (same ld) is allowed as in the reference.
+ * `hip_stream` is a hipStream_t (NULL = default stream); the call enqueues
+ * and returns.  n == 0 is a no-op. */
+EXPORT int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out,
+                                const double *in, size_t ld_in, size_t n, void *hip_stream);
+
+/* RTFilter_reset on every channel (state untouched, src/RTFilter.c:55-58). */
+EXPORT int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream);
+
+/* Copy device state into the host structs given to _from_filters so that they
+ * hold what the reference would have left (state[], filtered_value,
+ * initialized).  Synchronises the stream. */
+EXPORT int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream);
+
+/* Raw state access (host buffers): state is nch x ld doubles (row c = channel c,
+ * first max(na,nb) / nb entries meaningful), fval nch doubles, init nch ints. */
+EXPORT size_t RTFilterBank_state_ld(const RTFilterBank *bank);
+EXPORT int RTFilterBank_get_state(RTFilterBank *bank, double *state, double *fval, int32_t *init,
+                                  void *hip_stream);
+EXPORT int RTFilterBank_set_state(RTFilterBank *bank, const double *state, const double *fval,
+                                  const int32_t *init, void *hip_stream);
+
+/* Thread-local description of the last failure in this API. */
+EXPORT const char *RTFilterBank_last_error(void);
+
+/* ---- device memory pool --------------------------------------------------
+ * Size-bucketed caching allocator over hipMalloc for sample blocks and bank
+ * tables (sized for 288 GB of HBM3E: blocks are reused, not re-allocated per
+ * call).  Thread-safe. */
+EXPORT int    dsp_pool_alloc(void **dev_ptr, size_t bytes, int device);
+EXPORT int    dsp_pool_free(void *dev_ptr);
+EXPORT int    dsp_pool_trim(int device);               /* release cached blocks to the driver */
+EXPORT size_t dsp_pool_bytes_in_use(int device);
+EXPORT size_t dsp_pool_bytes_cached(int device);
+
+/* ---- helpers for harnesses ------------------------------------------------
+ * Deterministic synthetic input:
+ *   x[c][k] = (double)(int64)(splitmix64(seed ^ ((chan0+c) << 32) + (n0+k)) >> 11) * 2^-52 - 1
+ * written on device to dst + c*ld + k, c < nch, k < n. */
+EXPORT int dsp_synth_fill(double *dst, size_t ld, size_t nch, size_t n,
+                          uint64_t seed, uint64_t chan0, uint64_t n0, void *hip_stream);
+EXPORT int dsp_device_count(void);
+EXPORT int dsp_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device);
+EXPORT int dsp_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device);
+EXPORT int dsp_stream_synchronize(void *hip_stream, int device);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RTFILTERBANK_H */

@@ -1,0 +1,218 @@
+"""GPU parity tests for the IIR kernels, through the C ABI (RTFilterBank_*).
+
+Bars: sequential kernel BIT-EXACT vs the oracle (and vs the reference's own golden
+outputs); scan kernel max|dy|/max|y_ref| <= 1e-12 per channel on the pinned well-conditioned designs.
+"""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCAN = 1e-12   # north_star: "within 1e-12 relative error in float64"
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests import gpu_util
+    gpu_util.torch_mod()
+    return gpu_util
+
+
+def test_synth_fill_matches_checker(G):
+    torch = G.torch_mod()
+    from dsp_amd import bank as gbank
+    t = torch.empty((5, 1000), dtype=torch.float64, device="cuda")
+    gbank.synth_fill(t, 0x5EED0002, chan0=3, n0=77)
+    ref = np.stack([util.synth(0x5EED0002, 3 + c, 77, 1000) for c in range(5)])
+    assert util.bits_equal(t.cpu().numpy(), ref)
+
+
+IIR_KEYS = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "bw2_bp_demo", "bw5_lp_0.25", "bw3_hp_0.4",
+            "bw3_bs_0.6_0.3", "ch1_4_lp_0.3", "bw1_lp_0.1", "bw16_lp_0.5", "thiran_5_4"]
+
+
+@pytest.mark.parametrize("key", IIR_KEYS)
+def test_sequential_bit_exact_vs_reference_golden(G, key):
+    """One channel through the GPU sequential kernel == the reference's own output, bit for bit."""
+    from dsp_amd import bank as gbank
+    runs = util.load_npz("runs.npz")
+    if key + "/y" not in runs.files:
+        pytest.skip("no golden run for " + key)
+    yref = runs[key + "/y"]
+    x = util.synth(int(runs[key + "/seed"][0]), 0, 0, len(yref))
+    gb = gbank.FilterBank([G.golden_design(key)], [0], mode=gbank.MODE_SEQUENTIAL)
+    pos, outs = 0, []
+    for cut in runs[key + "/cuts"]:
+        cut = int(cut)
+        outs.append(gb(G.to_dev(x[None, pos:cut])).cpu().numpy()[0])
+        st, fv, ini = gb.get_state()
+        ref_state = runs["%s/state@%d" % (key, cut)]
+        assert util.bits_equal(st[0, :len(ref_state)], ref_state), (key, cut)
+        assert util.bits_equal(fv, runs["%s/fv@%d" % (key, cut)])
+        assert ini[0] == runs["%s/init@%d" % (key, cut)][0]
+        pos = cut
+    assert util.bits_equal(np.concatenate(outs), yref)
+    # RTFilter_reset leaves state stale, then a new stream
+    gb.reset()
+    x2 = util.synth(int(runs[key + "/seed_after_reset"][0]), 1, 0, len(runs[key + "/y_after_reset"]))
+    assert util.bits_equal(gb(G.to_dev(x2[None])).cpu().numpy()[0], runs[key + "/y_after_reset"])
+
+
+@pytest.mark.parametrize("blocks", [[1], [2, 1], [31, 33], [64, 1000, 7], [4096 + 17, 515]])
+def test_sequential_bit_exact_multichannel(G, blocks):
+    from dsp_amd import bank as gbank
+    designs = [G.golden_design(k) for k in ("bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "bw3_hp_0.4",
+                                            "thiran_5_4", "bw1_lp_0.1")]
+    nch = 203                                    # not a multiple of 64; interleaved designs => index lists
+    idx = [(3 * c + c // 7) % len(designs) for c in range(nch)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, blocks, gbank.MODE_SEQUENTIAL, seed=99)
+    for yg, yo in zip(ys_g, ys_o):
+        assert util.bits_equal(yg, yo)
+    G.assert_state_equal(gb, ob, exact=True)
+
+
+def test_sequential_kats_a0_not_one_and_ragged_taps(G):
+    """a0 != 1 (true divide) and nb != na (generic kernel)."""
+    from dsp_amd import bank as gbank
+    kats = util.load_json("kats.json")
+    cases = [("kat1_iir", [0.2, 0.3, 0.1], [1, -0.5, 0.25]), ("kat2_iir_a0", [0.2, 0.3, 0.1], [2, -1, 0.5]),
+             ("kat3_iir_nb_lt_na", [0.5], [1, -0.5, 0.25]), ("kat4_iir_nb_gt_na", [0.1, 0.2, 0.3, 0.4], [1, -0.3])]
+    designs = [gbank.iir_design(b, a) for _, b, a in cases]
+    gb = gbank.FilterBank(designs, list(range(len(cases))), mode=gbank.MODE_SEQUENTIAL)
+    x = np.tile(np.arange(1.0, 7.0), (len(cases), 1))
+    y = gb(G.to_dev(x)).cpu().numpy()
+    st, fv, ini = gb.get_state()
+    for c, (name, b, a) in enumerate(cases):
+        assert util.bits_equal(y[c], util.unhex(kats[name]["y"])), name
+        ref_state = util.unhex(kats[name]["state"])
+        assert util.bits_equal(st[c, :len(ref_state)], ref_state), name
+        assert ini[c] == 0
+
+
+def test_sequential_random_coefficients_and_a0(G):
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(3)
+    designs = []
+    for n in (2, 3, 5, 9, 12, 17):
+        b = rng.standard_normal(n)
+        a = rng.standard_normal(n) * 0.1
+        a[0] = rng.choice([1.0, 2.0, -0.5, 3.7])
+        designs.append(gbank.iir_design(b, a))
+    idx = [c % len(designs) for c in range(70)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, [130, 61], gbank.MODE_SEQUENTIAL, seed=5)
+    for yg, yo in zip(ys_g, ys_o):
+        assert util.bits_equal(yg, yo)
+    G.assert_state_equal(gb, ob, exact=True)
+
+
+def test_sequential_leading_zero_samples_keep_zero_signs(G):
+    """Streams that start with exact zeros exercise the reference's `0.0 + b*x` sign behaviour."""
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    d = G.golden_design("bw4_bp_0.3_0.6")
+    x = util.synth(17, 0, 0, 300)
+    x[:40] = 0.0
+    x[5] = -0.0
+    x[100:120] = -0.0
+    gb = gbank.FilterBank([d], [0, 0], mode=gbank.MODE_SEQUENTIAL)
+    xx = np.stack([x, -x])
+    y = gb(G.to_dev(xx)).cpu().numpy()
+    for c in range(2):
+        assert util.bits_equal(y[c], orc.iir(d["b"], d["a"]).updaten(xx[c]))
+
+
+@pytest.mark.parametrize("key,blocks", [
+    ("bw4_bp_0.3_0.6", [64 * 64 * 3]),                  # full segments only
+    ("bw4_bp_0.3_0.6", [1, 5, 64 * 64 + 1, 100, 9000]),  # seed alone, ragged tails, carry across blocks
+    ("bw8_bp_0.25_0.75", [5000, 64 * 64 * 2, 333]),
+    ("bw5_lp_0.25", [4097, 4095]),
+    ("bw2_bp_demo", [3000]),
+])
+def test_scan_within_1e12_of_oracle(G, key, blocks):
+    from dsp_amd import bank as gbank
+    designs = [G.golden_design(key)]
+    nch = 9
+    ys_g, ys_o, gb, ob = G.run_pair(designs, [0] * nch, blocks, gbank.MODE_SCAN, seed=31)
+    yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+    err = util.rel_to_peak(yg, yo)
+    assert np.all(err <= TOL_SCAN), (key, err.max())
+    G.assert_state_equal(gb, ob, exact=False, tol=1e-12)
+
+
+def test_scan_mixed_orders_noncontiguous_groups(G):
+    from dsp_amd import bank as gbank
+    keys = ("bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "bw3_hp_0.4", "bw16_lp_0.5")
+    designs = [G.golden_design(k) for k in keys]
+    idx = [c % 4 for c in range(22)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, [64 * 64 + 77, 2000], gbank.MODE_SCAN, seed=8)
+    yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+    assert np.all(util.rel_to_peak(yg, yo) <= TOL_SCAN)
+
+
+def test_unaligned_pointers_and_inplace(G):
+    """Odd leading dimension / 8-byte-aligned base take the scalar access path; in == out allowed."""
+    torch = G.torch_mod()
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    d = G.golden_design("bw4_bp_0.3_0.6")
+    nch, n, ld = 5, 5001, 5003
+    x = G.make_inputs(21, nch, n)
+    for mode, exact in ((gbank.MODE_SEQUENTIAL, True), (gbank.MODE_SCAN, False)):
+        buf = torch.zeros(nch * ld + 1, dtype=torch.float64, device="cuda")
+        view = buf[1:].view(nch, ld)[:, :n]          # base 8-byte aligned only, odd ld
+        view.copy_(G.to_dev(x))
+        gb = gbank.FilterBank([d], [0] * nch, mode=mode)
+        gb(view, out=view)                            # in place
+        y = view.cpu().numpy()
+        yo = orc.Bank([G.to_orc_design(d)], [0] * nch).updaten(x)
+        if exact:
+            assert util.bits_equal(y, yo)
+        else:
+            assert np.all(util.rel_to_peak(y, yo) <= TOL_SCAN)
+
+
+def test_from_filters_and_sync_to_host(G):
+    """Bank built from host structs; after sync the structs hold what the reference would have left."""
+    from dsp_amd import bank as gbank, dsp
+    from oracle import oracle as orc
+    _, b, a = util.design_coefs("bw4_bp_0.3_0.6")
+    filters = [dsp.RTIIRFilter(list(b), list(a)) for _ in range(3)]
+    x = G.make_inputs(77, 3, 700)
+    # channel 1 already consumed 100 samples on the host before the bank takes over
+    pre = filters[1](x[1, :100].tolist())
+    gb = gbank.FilterBank.from_filters(filters, mode=gbank.MODE_SEQUENTIAL)
+    xin = x.copy()
+    xin[1, :600] = x[1, 100:]
+    y = gb(G.to_dev(xin[:, :600])).cpu().numpy()
+    gb.sync_to_host()
+    for c in range(3):
+        o = orc.iir(b, a)
+        if c == 1:
+            yo = o.updaten(x[1])
+            assert util.bits_equal(pre, yo[:100]) and util.bits_equal(y[1], yo[100:])
+        else:
+            yo = o.updaten(x[c, :600])
+            assert util.bits_equal(y[c], yo)
+        assert util.bits_equal(np.array(filters[c].state()), o.state)
+        assert filters[c].filtered_value == o.filtered_value and filters[c].initialized == 0
+    # and the host path continues seamlessly from the synced state
+    nxt = filters[0](x[0, 600:].tolist())
+    o = orc.iir(b, a); o.updaten(x[0, :600])
+    assert util.bits_equal(nxt, o.updaten(x[0, 600:]))
+
+
+def test_pool_reuses_blocks(G):
+    import ctypes as C
+    from dsp_amd.cdsp import dspdll
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    assert dspdll.dsp_pool_alloc(C.byref(p1), 3 << 20, 0) == 0
+    used = dspdll.dsp_pool_bytes_in_use(0)
+    assert dspdll.dsp_pool_free(p1) == 0
+    assert dspdll.dsp_pool_bytes_cached(0) >= (3 << 20)
+    assert dspdll.dsp_pool_alloc(C.byref(p2), 3 << 20, 0) == 0
+    assert p2.value == p1.value and dspdll.dsp_pool_bytes_in_use(0) == used
+    assert dspdll.dsp_pool_free(p2) == 0
+    assert dspdll.dsp_pool_free(C.c_void_p(12345)) != 0      # foreign pointer rejected
+    assert dspdll.dsp_pool_trim(0) == 0
