@@ -27,6 +27,38 @@ if not _os.path.exists(LIBRARY_PATH):
         "dsp_amd: %s not found. Build it with `make -C dsp_amd/csrc` "
         "(or __graft_entry__.build()); there is no fallback implementation." % LIBRARY_PATH)
 
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) next to
+    libtorch_hip.so, while libdsp.so is linked against the system ROCm's libamdhip64.so.7.  If both
+    copies get loaded the second one finds "no ROCm-capable device".  Loading torch's copy first --
+    by path, without importing torch -- makes the dynamic linker satisfy libdsp.so's NEEDED entry
+    with it (SONAME match), and a later `import torch` finds the very same object.  Without torch
+    installed libdsp.so simply uses the system runtime.
+    """
+    import importlib.util
+    import sys
+    override = _os.environ.get("DSP_AMD_HIP_RUNTIME")
+    if override:
+        _C.CDLL(override, mode=_C.RTLD_GLOBAL)
+        return
+    if "torch" in sys.modules:
+        return                      # already loaded: SONAME match happens by itself
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = _os.path.join(_os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if _os.path.exists(cand):
+        _C.CDLL(cand, mode=_C.RTLD_GLOBAL)
+
+
+_share_hip_runtime_with_torch()
 dspdll = _C.CDLL(LIBRARY_PATH)
 
 
@@ -90,6 +122,10 @@ _proto("RTFilter_updaten", c_int, [_dp, POINTER(RTFilter_), _dp, c_size_t])
 _proto("RTIIRFilter_init", None, [POINTER(RTIIRFilter_), _dp, _dp, c_size_t, c_size_t, c_uint, _cb])
 _proto("RTFIRFilter_init", None, [POINTER(RTFIRFilter_), _dp, _dp, c_size_t, c_uint, _cb])
 _proto("moving_average", c_int, [POINTER(RTFIRFilter_), c_size_t, _cb])
+_proto("butterworth", c_int, [POINTER(RTIIRFilter_), c_size_t, c_double, c_double, c_uint, _cb])
+_proto("chebyshev1", c_int, [POINTER(RTIIRFilter_), c_size_t, c_double, c_double, c_double, c_uint, _cb])
+_proto("chebyshev2", c_int, [POINTER(RTIIRFilter_), c_size_t, c_double, c_double, c_double, c_uint, _cb])
+_proto("thiran", c_int, [POINTER(RTIIRFilter_), c_size_t, c_double, _cb])
 
 # ---- the rest of include/RTFilter.h that Python callers use ---------------------------------
 _proto("RTFilter_reset", None, [POINTER(RTFilter_)])
@@ -104,6 +140,7 @@ RTFB_MODE_AUTO, RTFB_MODE_SEQUENTIAL, RTFB_MODE_SCAN = 0, 1, 2
 _proto("RTFilterBank_from_filters", c_int, [POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int])
 _proto("RTFilterBank_from_designs", c_int,
        [POINTER(c_void_p), POINTER(RTFilterDesign_), c_size_t, POINTER(c_int32), c_size_t, c_int])
+_proto("dsp_scan_probe", c_int, [POINTER(RTFilterDesign_), POINTER(c_double)])
 _proto("RTFilterBank_destroy", None, [c_void_p])
 _proto("RTFilterBank_channels", c_size_t, [c_void_p])
 _proto("RTFilterBank_set_mode", c_int, [c_void_p, c_int])

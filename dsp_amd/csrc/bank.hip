@@ -14,6 +14,7 @@
  */
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -184,6 +185,8 @@ struct Design {
     std::vector<double> b, a;
     int coef_off = 0;
     int pow_off = 0;
+    double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
+    bool scan_safe() const;
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
     bool fast_iir() const
     {
@@ -191,17 +194,23 @@ struct Design {
     }
 };
 
-enum GroupClass { kIirFast = 0, kIirGeneric = 1 };
+enum GroupClass { kIirFast = 0, kIirGeneric = 1, kFir = 2 };
 
 struct Group {
     GroupClass cls;
     int order = 0;                      /* kIirFast: N */
+    bool scan_safe = false;             /* kIirFast: every design passed the conditioning probe */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
     int state_ld = 1;
     /* device */
     int32_t *d_chan = nullptr;
     int32_t *d_design = nullptr;
     double *d_state = nullptr;
+    double *d_state_alt = nullptr;      /* FIR: other half of the state ping-pong */
+    int32_t *d_aux = nullptr;           /* FIR: prologue -> main/epilogue hand-off */
+    int kmax = 0;                       /* FIR: longest filter in the group        */
+    double *d_scratch = nullptr;        /* FIR, in-place calls: private copy of the input */
+    size_t scratch_doubles = 0;
     double *d_fval = nullptr;
     int32_t *d_init = nullptr;
     bool contiguous = false;
@@ -257,12 +266,101 @@ void scan_powers(const Design &d, int T, std::vector<double> &out)
     }
 }
 
+/* Conditioning probe for the scan kernel (host, bank-creation time only; it
+ * produces no output sample).  The scan kernel re-associates the recurrence
+ * (zero-state pass + prefix combine with A^(T 2^k)), so its distance from the
+ * reference's sequential arithmetic depends on the design's conditioning
+ * (SURVEY.md 0.5): ~1e-16 for the well-conditioned designs, 1e-8 and worse for
+ * narrow-band / high-Q ones.  This runs the kernel's algorithm and the plain
+ * recurrence side by side on two segments of pseudo-random input and returns
+ * max|dy| / max|y|.  RTFB_MODE_AUTO sends a design to the scan kernel only if
+ * the probe stays below kScanSafeError; otherwise its channels run on the
+ * bit-exact sequential kernel. */
+constexpr double kScanSafeError = 1e-13;     /* 10x margin under the 1e-12 parity bar */
+
+bool Design::scan_safe() const { return scan_error <= kScanSafeError; }
+
+double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
+{
+    const int N = d.nb - 1, T = kScanT, L = 2 * kWave * kScanT;
+    std::vector<double> x(L), yref(L), y(L);
+    uint64_t z = 0x243F6A8885A308D3ull;
+    for (int k = 0; k < L; ++k) {                /* splitmix64 stream in [-1, 1) */
+        z += 0x9E3779B97F4A7C15ull;
+        uint64_t h = z;
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+        x[k] = (double)(int64_t)(h >> 11) * 0x1.0p-52 - 1.0;
+    }
+    const double *b = d.b.data(), *a = d.a.data();
+    auto step = [&](double xv, double *s) {      /* reference order, as iir_step_ref */
+        double t = xv * b[0];
+        t = t + s[0];
+        const double yv = t / a[0];
+        for (int i = 0; i < N; ++i) {
+            double u = 0.0 + b[i + 1] * xv;
+            u = u - a[i + 1] * yv;
+            s[i] = s[i + 1] + u;
+        }
+        return yv;
+    };
+    auto step_fused = [&](double xv, double *s) {   /* as iir_step_fused */
+        double yv = std::fma(xv, b[0], s[0]);
+        if (a[0] != 1.0) yv = yv / a[0];
+        for (int i = 0; i < N; ++i) s[i] = std::fma(-a[i + 1], yv, std::fma(b[i + 1], xv, s[i + 1]));
+    };
+    std::vector<double> sref(N + 1, 0.0);
+    for (int k = 0; k < L; ++k) yref[k] = step(x[k], sref.data());
+
+    std::vector<double> carry(N + 1, 0.0);
+    std::vector<std::vector<double>> v(kWave, std::vector<double>(N + 1));
+    for (int seg = 0; seg < L / (kWave * T); ++seg) {
+        const double *xs = &x[(size_t)seg * kWave * T];
+        double *ys = &y[(size_t)seg * kWave * T];
+        for (int j = 0; j < kWave; ++j) {
+            for (int i = 0; i < N; ++i) v[j][i] = j == 0 ? carry[i] : 0.0;
+            v[j][N] = carry[N];
+            for (int k = 0; k < T; ++k) step_fused(xs[j * T + k], v[j].data());
+        }
+        for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+            const int dist = 1 << lvl;
+            const double *M = &pows_of_design[(size_t)lvl * N * N];
+            for (int j = kWave - 1; j >= dist; --j)
+                for (int i = 0; i < N; ++i) {
+                    double acc = v[j][i];
+                    for (int q = 0; q < N; ++q) acc = std::fma(M[i * N + q], v[j - dist][q], acc);
+                    v[j][i] = acc;              /* j descending: v[j-dist] is still the old value */
+                }
+        }
+        std::vector<double> s(N + 1), next(N + 1);
+        for (int j = 0; j < kWave; ++j) {
+            for (int i = 0; i < N; ++i) s[i] = j == 0 ? carry[i] : v[j - 1][i];
+            s[N] = carry[N];
+            for (int k = 0; k < T; ++k) ys[j * T + k] = step(xs[j * T + k], s.data());
+            if (j == kWave - 1) next = s;
+        }
+        carry = next;
+    }
+    double peak = 0.0, err = 0.0;
+    for (int k = 0; k < L; ++k) {
+        peak = std::max(peak, std::fabs(yref[k]));
+        const double e = std::fabs(y[k] - yref[k]);
+        if (!(e <= err)) err = e;               /* NaN-propagating max */
+    }
+    if (!(peak > 0.0)) return err == 0.0 ? 0.0 : HUGE_VAL;
+    return err / peak;
+}
+
 void free_bank_device(RTFilterBank *b)
 {
     for (Group &g : b->groups) {
         pool_free(g.d_chan);
         pool_free(g.d_design);
         pool_free(g.d_state);
+        pool_free(g.d_state_alt);
+        pool_free(g.d_aux);
+        pool_free(g.d_scratch);
         pool_free(g.d_fval);
         pool_free(g.d_init);
     }
@@ -294,7 +392,11 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         coefs.insert(coefs.end(), d.b.begin(), d.b.end());
         coefs.insert(coefs.end(), d.a.begin(), d.a.end());
         d.pow_off = (int)pows.size();
-        if (d.fast_iir()) scan_powers(d, kScanT, pows);
+        if (d.fast_iir()) {
+            scan_powers(d, kScanT, pows);
+            const std::vector<double> mine(pows.begin() + d.pow_off, pows.end());
+            d.scan_error = scan_probe(d, mine);
+        }
         coef_off.push_back(d.coef_off);
         pow_off.push_back(d.pow_off);
         nb.push_back(d.nb);
@@ -309,21 +411,22 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     for (size_t c = 0; c < bk->nch; ++c) {
         const Design &d = bk->designs[bk->design_of[c]];
         std::pair<int, int> key;
-        if (d.kind != RTFB_KIND_IIR)
-            return fail(RTFB_EUNSUPPORTED, "FIR channels are not built into this library yet");
-        if (d.fast_iir()) key = {kIirFast, d.nb - 1};
+        if (d.kind != RTFB_KIND_IIR) key = {kFir, 0};
+        else if (d.fast_iir()) key = {kIirFast, 2 * (d.nb - 1) + (d.scan_safe() ? 1 : 0)};
         else key = {kIirGeneric, 0};
         auto it = index.find(key);
         if (it == index.end()) {
             Group g;
             g.cls = (GroupClass)key.first;
-            g.order = key.second;
+            g.order = key.second / 2;
+            g.scan_safe = key.second & 1;
             it = index.emplace(key, bk->groups.size()).first;
             bk->groups.push_back(g);
         }
         Group &g = bk->groups[it->second];
         g.chans.push_back((int32_t)c);
         g.state_ld = std::max(g.state_ld, d.state_slots());
+        if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
     }
 
     int rc;
@@ -354,6 +457,11 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         if (!g.contiguous && (rc = upload(&g.d_chan, g.chans, device))) return rc;
         if ((rc = upload(&g.d_design, dsn, device))) return rc;
         if ((rc = upload(&g.d_state, st, device))) return rc;
+        if (g.cls == kFir) {
+            if ((rc = upload(&g.d_state_alt, st, device))) return rc;
+            std::vector<int32_t> aux(2 * cnt, 0);
+            if ((rc = upload(&g.d_aux, aux, device))) return rc;
+        }
         if ((rc = upload(&g.d_fval, fv, device))) return rc;
         if ((rc = upload(&g.d_init, ini, device))) return rc;
     }
@@ -368,7 +476,10 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.count = (int32_t)g.chans.size();
     v.design = g.d_design;
     v.state = g.d_state;
+    v.state_out = g.d_state_alt;
     v.state_ld = g.state_ld;
+    v.aux = g.d_aux;
+    v.kmax = g.kmax;
     v.fval = g.d_fval;
     v.init = g.d_init;
     v.coef_off = bk->d_coef_off;
@@ -394,6 +505,8 @@ int validate_design(const RTFilterDesign &d)
         if (!d.a || d.na == 0) return fail(RTFB_EINVAL, "IIR design needs at least one a tap");
         if (d.nb > (size_t)kMaxGenericTaps || d.na > (size_t)kMaxGenericTaps)
             return fail(RTFB_ESIZE, "IIR design exceeds 64 taps");
+    } else if (d.nb > (size_t)kMaxFirTaps) {
+        return fail(RTFB_ESIZE, "FIR design exceeds 4096 taps");
     }
     return RTFB_OK;
 }
@@ -482,6 +595,24 @@ int dsp_synth_fill(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed, 
     if (!dst && nch * n) return fail(RTFB_EINVAL, "dsp_synth_fill: NULL destination");
     if (ld < n) return fail(RTFB_EINVAL, "dsp_synth_fill: ld < n");
     HIP_TRY(launch_synth(dst, ld, nch, n, seed, chan0, n0, static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int dsp_scan_probe(const RTFilterDesign *design, double *rel_error)
+{
+    if (!design || !rel_error) return fail(RTFB_EINVAL, "dsp_scan_probe: NULL argument");
+    int rc = validate_design(*design);
+    if (rc) return rc;
+    Design d;
+    d.kind = design->kind;
+    d.nb = (int)design->nb;
+    d.na = d.kind == RTFB_KIND_IIR ? (int)design->na : 0;
+    d.b.assign(design->b, design->b + d.nb);
+    if (d.na) d.a.assign(design->a, design->a + d.na);
+    if (!d.fast_iir()) return fail(RTFB_EUNSUPPORTED, "the scan kernel takes IIR designs with na == nb <= 17");
+    std::vector<double> pows;
+    scan_powers(d, kScanT, pows);
+    *rel_error = scan_probe(d, pows);
     return RTFB_OK;
 }
 
@@ -651,14 +782,44 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
     io.aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) &&
                    ld_in % 2 == 0 && ld_out % 2 == 0;
 
-    for (const Group &g : bank->groups) {
-        const GroupView v = view_of(bank, g);
+    for (Group &g : bank->groups) {
+        GroupView v = view_of(bank, g);
+        if (g.cls == kFir) {
+            /* FIR outputs are computed out of order in time, so the kernels must not see their
+             * own outputs as inputs: an in-place call (allowed by the reference, where each
+             * sample is read before its slot is written) reads from a private copy instead. */
+            BlockIO fio = io;
+            const double *in_end = in + (bank->nch - 1) * ld_in + n;
+            const double *out_end = out + (bank->nch - 1) * ld_out + n;
+            if (in < out_end && out < in_end) {
+                const size_t need = bank->nch * n;
+                if (g.scratch_doubles < need) {
+                    HIP_TRY(hipStreamSynchronize(s));
+                    pool_free(g.d_scratch);
+                    g.d_scratch = nullptr;
+                    g.scratch_doubles = 0;
+                    void *p = nullptr;
+                    int rc = pool_alloc(&p, need * sizeof(double), bank->device);
+                    if (rc) return rc;
+                    g.d_scratch = static_cast<double *>(p);
+                    g.scratch_doubles = need;
+                }
+                HIP_TRY(hipMemcpy2DAsync(g.d_scratch, n * sizeof(double), in, ld_in * sizeof(double),
+                                         n * sizeof(double), bank->nch, hipMemcpyDeviceToDevice, s));
+                fio.in = g.d_scratch;
+                fio.ld_in = n;
+            }
+            HIP_TRY(launch_fir(v, fio, s));
+            std::swap(g.d_state, g.d_state_alt);
+            continue;
+        }
         if (g.cls == kIirGeneric) {
             HIP_TRY(launch_iir_generic(v, io, s));
             continue;
         }
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
-                   (bank->mode == RTFB_MODE_AUTO && g.chans.size() >= kAutoSeqMinChannels);
+                   (bank->mode == RTFB_MODE_AUTO &&
+                    (g.chans.size() >= kAutoSeqMinChannels || !g.scan_safe));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
         else HIP_TRY(launch_iir_scan(g.order, v, io, s));

@@ -18,6 +18,10 @@ constexpr int kScanLevels = 6;       /* log2(kWave): Kogge-Stone steps across a 
  * 64 rows x T doubles staged through LDS with one 16-byte pad per row. */
 constexpr int kSeqT = 32;            /* sequential kernel: rows are channels          */
 constexpr int kScanT = 64;           /* scan kernel: rows are consecutive time chunks */
+constexpr int kFirT = 32;            /* FIR kernel: outputs per lane                  */
+constexpr int kFirR = 8;             /* FIR kernel: outputs accumulated together      */
+constexpr int kFirSeg = kWave * kFirT;   /* outputs per wavefront                    */
+constexpr int kMaxFirTaps = 4096;
 
 /* One launch group: channels of the bank that share a kernel. All pointers are
  * device pointers; arrays are indexed by the group-local channel index g. */
@@ -27,7 +31,12 @@ struct GroupView {
     int32_t        count;
     const int32_t *design;    /* design index per g                                       */
     double        *state;     /* count x state_ld                                         */
+    double        *state_out; /* FIR only: the block's end state is written here (ping-pong) */
     int32_t        state_ld;
+    int32_t       *aux;       /* FIR only: 2 ints per g written by the prologue: first regular
+                                 sample t0 (1 if sample 0 went to stable_init) and the stream
+                                 index of the block's sample 0 while a partial_init ramp runs */
+    int32_t        kmax;      /* FIR only: largest tap count in the group                 */
     double        *fval;      /* RTFilter.filtered_value per g                            */
     int32_t       *init;      /* RTFilter.initialized per g                               */
     const int32_t *coef_off;  /* per design: offset of b[0] in coefs (a follows b)        */
@@ -52,6 +61,7 @@ struct BlockIO {
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_reset(const GroupView &g, hipStream_t s);
 hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
                         uint64_t chan0, uint64_t n0, hipStream_t s);

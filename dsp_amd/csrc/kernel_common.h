@@ -1,0 +1,34 @@
+/* kernel_common.h -- device-side helpers shared by the kernel translation units. */
+#ifndef DSP_KERNEL_COMMON_H
+#define DSP_KERNEL_COMMON_H
+
+#include "dsp_internal.h"
+
+namespace dsp {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+/* Read-only tables (coefficients, matrix powers, design indices) are read
+ * through the constant address space so that wave-uniform loads become scalar
+ * loads (s_load_*) into SGPRs even though the kernel also stores to global
+ * memory; the bank never aliases its tables with sample buffers. */
+typedef const double __attribute__((address_space(4))) *cdouble_p;
+typedef const int32_t __attribute__((address_space(4))) *cint_p;
+__device__ __forceinline__ cdouble_p as_const(const double *p)
+{
+    return (cdouble_p)(uintptr_t)p;
+}
+__device__ __forceinline__ cint_p as_const(const int32_t *p)
+{
+    return (cint_p)(uintptr_t)p;
+}
+
+__device__ __forceinline__ int group_channel(const GroupView &g, int idx)
+{
+    return g.chan ? g.chan[idx] : g.chan0 + idx;
+}
+
+
+}  // namespace dsp
+
+#endif

@@ -129,6 +129,51 @@ class RTFIRFilter(_RTFilterObject):
         return tuple(self._state[: self._rtff.ifb.nb])
 
 
+def _two_edges(wlow, whigh):
+    return 2 if wlow > 0.0 and whigh > 0.0 else 1
+
+
+def _design(name, order, nb, na, call, flags, initialize):
+    if initialize is not None:
+        initialize = cdsp.i_RTFilter__d(initialize)
+    rtif = RTIIRFilter([0.0] * nb, [0.0] * na, flags, initialize)
+    status = call(rtif, initialize)
+    if status:
+        raise ValueError("%s: status %d" % (name, status))
+    rtif.nb, rtif.na = rtif.cobj().ifb.fb.nb, rtif.cobj().ifb.na
+    return rtif
+
+
+def butterworth(order, wlow, whigh, flags=0, initialize=None):
+    """python/dsp.py:79-87: bank of order*(2 if band else 1)+1 taps each for b and a."""
+    n = order * _two_edges(wlow, whigh) + 1
+    return _design("butterworth", order, n, n,
+                   lambda f, cb: dspdll.butterworth(byref_(f.cobj()), order, wlow, whigh, flags, byref_(cb)),
+                   flags, initialize)
+
+
+def chebyshev1(order, ripple, wlow, whigh, flags=0, initialize=None):
+    """python/dsp.py:98-106, with `ripple` actually passed to C (the reference omits it)."""
+    n = order * _two_edges(wlow, whigh) + 1
+    return _design("chebyshev1", order, n, n,
+                   lambda f, cb: dspdll.chebyshev1(byref_(f.cobj()), order, ripple, wlow, whigh, flags, byref_(cb)),
+                   flags, initialize)
+
+
+def chebyshev2(order, ripple, wlow, whigh, flags=0, initialize=None):
+    """python/dsp.py:108-116, with `ripple` passed."""
+    n = order * _two_edges(wlow, whigh) + 1
+    return _design("chebyshev2", order, n, n,
+                   lambda f, cb: dspdll.chebyshev2(byref_(f.cobj()), order, ripple, wlow, whigh, flags, byref_(cb)),
+                   flags, initialize)
+
+
+def thiran(order, tau, flags=0, initialize=None):
+    """python/dsp.py:89-96: b has one tap, a has order+1."""
+    return _design("thiran", order, 1, order + 1,
+                   lambda f, cb: dspdll.thiran(byref_(f.cobj()), order, tau, byref_(cb)), flags, initialize)
+
+
 def moving_average(window, initialize=None):
     """python/dsp.py:118-124 (with the undefined `flags` fixed): window equal taps, ramp-in init."""
     if initialize is not None:

@@ -74,6 +74,12 @@ EXPORT int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *
                                      size_t ndesign, const int32_t *design_of_channel,
                                      size_t nch, int device);
 
+/* Conditioning probe used by RTFB_MODE_AUTO (host arithmetic, no device needed, produces no
+ * filter output): runs the scan kernel's re-associated algorithm against the plain recurrence on
+ * pseudo-random input and reports max|dy|/max|y|.  Designs above 1e-13 are kept on the sequential
+ * kernel in AUTO mode.  RTFB_EUNSUPPORTED unless IIR with na == nb <= 17. */
+EXPORT int dsp_scan_probe(const RTFilterDesign *design, double *rel_error);
+
 EXPORT void   RTFilterBank_destroy(RTFilterBank *bank);
 EXPORT size_t RTFilterBank_channels(const RTFilterBank *bank);
 EXPORT int    RTFilterBank_set_mode(RTFilterBank *bank, int mode);

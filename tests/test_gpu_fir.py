@@ -1,0 +1,128 @@
+"""GPU parity tests for the FIR kernels (stable_init and partial_init streams): BIT-EXACT vs the
+reference's golden outputs and vs the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests import gpu_util
+    gpu_util.torch_mod()
+    return gpu_util
+
+
+FIR_KEYS = ["fir512_lp_0.25", "fir32_lp_0.25", "fir7_lp_0.4", "mavg3", "mavg32", "mavg512"]
+
+
+@pytest.mark.parametrize("key", FIR_KEYS)
+def test_fir_bit_exact_vs_reference_golden(G, key):
+    from dsp_amd import bank as gbank
+    runs = util.load_npz("runs.npz")
+    yref = runs[key + "/y"]
+    x = util.synth(int(runs[key + "/seed"][0]), 0, 0, len(yref))
+    gb = gbank.FilterBank([G.golden_design(key)], [0])
+    pos, outs = 0, []
+    for cut in runs[key + "/cuts"]:
+        cut = int(cut)
+        outs.append(gb(G.to_dev(x[None, pos:cut])).cpu().numpy()[0])
+        st, fv, ini = gb.get_state()
+        ref_state = runs["%s/state@%d" % (key, cut)]
+        assert util.bits_equal(st[0, :len(ref_state)], ref_state), (key, cut)
+        assert util.bits_equal(fv, runs["%s/fv@%d" % (key, cut)]), (key, cut)
+        assert ini[0] == runs["%s/init@%d" % (key, cut)][0], (key, cut)
+        pos = cut
+    assert util.bits_equal(np.concatenate(outs), yref)
+    # RTFilter_reset leaves the delay line stale; partial_init then leaks it (SURVEY KAT8)
+    gb.reset()
+    x2 = util.synth(int(runs[key + "/seed_after_reset"][0]), 1, 0, len(runs[key + "/y_after_reset"]))
+    assert util.bits_equal(gb(G.to_dev(x2[None])).cpu().numpy()[0], runs[key + "/y_after_reset"])
+    st, _, _ = gb.get_state()
+    ref_state = runs[key + "/state_after_reset"]
+    assert util.bits_equal(st[0, :len(ref_state)], ref_state)
+
+
+def test_fir_kats(G):
+    from dsp_amd import bank as gbank
+    kats = util.load_json("kats.json")
+    x = np.arange(1.0, 7.0)
+    gb = gbank.FilterBank([gbank.fir_design([0.5, 0.3, 0.2]), gbank.fir_design([0.5, 0.3, 0.4]),
+                           G.golden_design("mavg3")], [0, 1, 2])
+    y = gb(G.to_dev(np.tile(x, (3, 1)))).cpu().numpy()
+    assert util.bits_equal(y[0], util.unhex(kats["kat5_fir"]["y"]))
+    assert util.bits_equal(y[1], util.unhex(kats["kat6_fir_sum12"]["y"]))
+    assert util.bits_equal(y[2], util.unhex(kats["kat7_mavg3_partial"]["y"]))
+    st, fv, ini = gb.get_state()
+    assert util.bits_equal(st[0, :3], util.unhex(kats["kat5_fir"]["state"]))
+    # KAT8: reset, same input again, stale state shows in sample 1
+    gb.reset()
+    y = gb(G.to_dev(np.tile(x, (3, 1)))).cpu().numpy()
+    assert util.bits_equal(y[2], util.unhex(kats["kat8_mavg3_reset_stale"]["y"]))
+    # one sample at a time (block length 1) through the same bank == KAT7 again after a clean start
+    gb2 = gbank.FilterBank([G.golden_design("mavg3")], [0])
+    y1 = np.concatenate([gb2(G.to_dev(x[None, i:i + 1])).cpu().numpy()[0] for i in range(6)])
+    assert util.bits_equal(y1, util.unhex(kats["kat7_mavg3_partial"]["y"]))
+
+
+@pytest.mark.parametrize("blocks", [[1, 1, 1, 2], [5, 26, 1, 600], [31, 32, 33], [2047, 2, 2049],
+                                    [510, 1, 1, 700], [6000, 4096 + 11]])
+def test_fir_bit_exact_multichannel_ragged_blocks(G, blocks):
+    """Block cuts below, at and above the tap counts; mixed tap counts and init modes in one group."""
+    from dsp_amd import bank as gbank
+    keys = ("fir512_lp_0.25", "fir32_lp_0.25", "fir7_lp_0.4", "mavg3", "mavg32", "mavg512")
+    designs = [G.golden_design(k) for k in keys]
+    rng = np.random.default_rng(2)
+    designs.append(gbank.fir_design(rng.standard_normal(1)))          # K = 1: pure gain
+    designs.append(gbank.fir_design(rng.standard_normal(2)))
+    designs.append(gbank.fir_design(rng.standard_normal(100), partial=True))
+    nch = 37
+    idx = [(5 * c + 1) % len(designs) for c in range(nch)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, blocks, gbank.MODE_AUTO, seed=64)
+    for i, (yg, yo) in enumerate(zip(ys_g, ys_o)):
+        assert util.bits_equal(yg, yo), i
+    G.assert_state_equal(gb, ob, exact=True)
+
+
+def test_mixed_iir_fir_bank_and_inplace(G):
+    torch = G.torch_mod()
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    designs = [G.golden_design("bw4_bp_0.3_0.6"), G.golden_design("fir32_lp_0.25"),
+               G.golden_design("mavg32"), G.golden_design("thiran_5_4")]
+    nch = 50
+    idx = [c % 4 for c in range(nch)]
+    gb = gbank.FilterBank(designs, idx, mode=gbank.MODE_SEQUENTIAL)
+    ob = orc.Bank([G.to_orc_design(d) for d in designs], idx)
+    pos = 0
+    for n in (3000, 41, 5000):
+        x = G.make_inputs(12, nch, n, pos)
+        buf = G.to_dev(x)
+        gb(buf, out=buf)                              # in place: FIR channels go through a copy
+        assert util.bits_equal(buf.cpu().numpy(), ob.updaten(x, threads=4))
+        pos += n
+    G.assert_state_equal(gb, ob, exact=True)
+
+
+def test_fir_from_filters_sync_to_host(G):
+    from dsp_amd import bank as gbank, dsp
+    from oracle import oracle as orc
+    _, b, _ = util.design_coefs("fir32_lp_0.25")
+    f_stable = dsp.RTFIRFilter(list(b))
+    f_ramp = dsp.moving_average(32)
+    x = G.make_inputs(3, 2, 500)
+    pre = f_ramp(x[1, :10].tolist())                 # ramp already running when the bank takes over
+    gb = gbank.FilterBank.from_filters([f_stable, f_ramp])
+    xin = np.stack([x[0, :400], x[1, 10:410]])
+    y = gb(G.to_dev(xin)).cpu().numpy()
+    gb.sync_to_host()
+    o0 = orc.fir(b)
+    assert util.bits_equal(y[0], o0.updaten(x[0, :400]))
+    o1 = orc.fir(np.full(32, 1.0 / 32), partial=True)
+    yo1 = o1.updaten(x[1, :410])
+    assert util.bits_equal(pre, yo1[:10]) and util.bits_equal(y[1], yo1[10:])
+    assert util.bits_equal(np.array(f_stable.state()), o0.state)
+    assert util.bits_equal(np.array(f_ramp.state()), o1.state)
+    assert f_ramp.initialized == 0 and f_ramp.filtered_value == o1.filtered_value

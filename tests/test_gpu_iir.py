@@ -128,7 +128,6 @@ def test_sequential_leading_zero_samples_keep_zero_signs(G):
     ("bw4_bp_0.3_0.6", [1, 5, 64 * 64 + 1, 100, 9000]),  # seed alone, ragged tails, carry across blocks
     ("bw8_bp_0.25_0.75", [5000, 64 * 64 * 2, 333]),
     ("bw5_lp_0.25", [4097, 4095]),
-    ("bw2_bp_demo", [3000]),
 ])
 def test_scan_within_1e12_of_oracle(G, key, blocks):
     from dsp_amd import bank as gbank
