@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -185,6 +186,9 @@ struct Design {
     std::vector<double> b, a;
     int coef_off = 0;
     int pow_off = 0;
+    int pow2_off = 0;
+    int levels2 = 0;
+    int gtab_off = 0;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
     bool scan_safe() const;
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
@@ -200,6 +204,7 @@ struct Group {
     GroupClass cls;
     int order = 0;                      /* kIirFast: N */
     bool scan_safe = false;             /* kIirFast: every design passed the conditioning probe */
+    bool unit_a0 = false;               /* kIirFast: every design has a[0] == 1.0               */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
     int state_ld = 1;
     /* device */
@@ -209,6 +214,7 @@ struct Group {
     double *d_state_alt = nullptr;      /* FIR: other half of the state ping-pong */
     int32_t *d_aux = nullptr;           /* FIR: prologue -> main/epilogue hand-off */
     int kmax = 0;                       /* FIR: longest filter in the group        */
+    int levels2_max = 0;                /* fast IIR: most combine levels any design needs */
     double *d_scratch = nullptr;        /* FIR, in-place calls: private copy of the input */
     size_t scratch_doubles = 0;
     double *d_fval = nullptr;
@@ -222,14 +228,15 @@ struct RTFilterBank {
     int device = 0;
     size_t nch = 0;
     int mode = RTFB_MODE_AUTO;
+    bool one_wave_scan = std::getenv("DSP_AMD_ONE_WAVE_SCAN") != nullptr;   /* A/B switch for profiling */
     std::vector<Design> designs;
     std::vector<int32_t> design_of;     /* per channel */
     std::vector<Group> groups;
     std::vector<RTFilter *> host_filters;   /* from_filters only */
     size_t state_ld = 1;                /* uniform ld of the get/set_state API */
     /* device tables shared by all groups */
-    int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_nb = nullptr, *d_na = nullptr,
-            *d_kind = nullptr;
+    int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_pow2_off = nullptr, *d_levels2 = nullptr, *d_gtab_off = nullptr,
+            *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
 };
 
@@ -239,7 +246,7 @@ namespace {
  * RTIIRFilter_update with x = 0 (ref: src/RTFilter.c:417-433):
  *   y = s0 / a0 ;  s_i' = s_{i+1} - a_{i+1} * y   =>  A = U - (a_{1..N}/a0) e0^T.
  * Computed in long double, stored as doubles, row-major. */
-void scan_powers(const Design &d, int T, std::vector<double> &out)
+void scan_powers(const Design &d, int T, int levels, std::vector<double> &out)
 {
     const int N = d.nb - 1;
     typedef std::vector<long double> Mat;
@@ -260,10 +267,62 @@ void scan_powers(const Design &d, int T, std::vector<double> &out)
     }
     Mat P = A;                                  /* A^1 -> A^T by squaring (T is a power of two) */
     for (int t = 1; t < T; t <<= 1) P = mul(P, P);
-    for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+    for (int lvl = 0; lvl < levels; ++lvl) {
         for (size_t e = 0; e < P.size(); ++e) out.push_back((double)P[e]);
         P = mul(P, P);
     }
+}
+
+/* Zero-state response table of the two-wave scan kernel.  With s' = A s + B x
+ * (B_i = b_{i+1} - a_{i+1} b0 / a0) the state a chunk of T samples leaves behind when it starts
+ * from zero is  sum_n A^(T-1-n) B x[n]:  N multiply-adds per sample instead of the 2N+1 of
+ * running the recurrence.  Gc is the same for a constant fed into the last delay slot (the
+ * reference's never-written state[N]).  Long double, stored as doubles: G[n][i] then Gc[i]. */
+void scan2_gtable(const Design &d, int T, std::vector<double> &out)
+{
+    const int N = d.nb - 1;
+    std::vector<long double> alpha(N), w(N), acc(N, 0.0L), e(N, 0.0L);
+    const long double a0 = d.a[0], b0 = d.b[0];
+    for (int i = 0; i < N; ++i) {
+        alpha[i] = (long double)d.a[i + 1] / a0;
+        w[i] = (long double)d.b[i + 1] - alpha[i] * b0;
+    }
+    auto advance = [&](std::vector<long double> &z) {       /* z <- A z */
+        const long double z0 = z[0];
+        for (int i = 0; i < N; ++i) z[i] = (i + 1 < N ? z[i + 1] : 0.0L) - alpha[i] * z0;
+    };
+    std::vector<double> table((size_t)T * N);
+    for (int n = T - 1; n >= 0; --n) {                       /* w = A^(T-1-n) B */
+        for (int i = 0; i < N; ++i) table[(size_t)n * N + i] = (double)w[i];
+        advance(w);
+    }
+    e[N - 1] = 1.0L;
+    for (int m = 0; m < T; ++m) {
+        for (int i = 0; i < N; ++i) acc[i] += e[i];
+        advance(e);
+    }
+    out.insert(out.end(), table.begin(), table.end());
+    for (int i = 0; i < N; ++i) out.push_back((double)acc[i]);
+}
+
+/* Combine levels of the two-wave scan kernel that still matter for a design:
+ * level k applies A^(32*2^k); once every entry of that power (and of all
+ * higher ones) is below 2^-75 its contribution is more than 2^-20 below one ulp
+ * of the state it is added to, and the kernel skips it. */
+constexpr double kScan2Negligible = 0x1.0p-75;
+
+int scan2_levels(const double *pw, int N)
+{
+    int need = 0;
+    for (int lvl = 0; lvl < kScan2Levels; ++lvl) {
+        double m = 0.0;
+        for (int e = 0; e < N * N; ++e) {
+            const double v = std::fabs(pw[(size_t)lvl * N * N + e]);
+            if (!(v <= m)) m = v;                /* NaN counts as large */
+        }
+        if (!(m < kScan2Negligible)) need = lvl + 1;
+    }
+    return need;
 }
 
 /* Conditioning probe for the scan kernel (host, bank-creation time only; it
@@ -309,6 +368,7 @@ double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
         double yv = std::fma(xv, b[0], s[0]);
         if (a[0] != 1.0) yv = yv / a[0];
         for (int i = 0; i < N; ++i) s[i] = std::fma(-a[i + 1], yv, std::fma(b[i + 1], xv, s[i + 1]));
+        return yv;
     };
     std::vector<double> sref(N + 1, 0.0);
     for (int k = 0; k < L; ++k) yref[k] = step(x[k], sref.data());
@@ -337,7 +397,7 @@ double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
         for (int j = 0; j < kWave; ++j) {
             for (int i = 0; i < N; ++i) s[i] = j == 0 ? carry[i] : v[j - 1][i];
             s[N] = carry[N];
-            for (int k = 0; k < T; ++k) ys[j * T + k] = step(xs[j * T + k], s.data());
+            for (int k = 0; k < T; ++k) ys[j * T + k] = step_fused(xs[j * T + k], s.data());
             if (j == kWave - 1) next = s;
         }
         carry = next;
@@ -366,6 +426,9 @@ void free_bank_device(RTFilterBank *b)
     }
     pool_free(b->d_coef_off);
     pool_free(b->d_pow_off);
+    pool_free(b->d_pow2_off);
+    pool_free(b->d_levels2);
+    pool_free(b->d_gtab_off);
     pool_free(b->d_nb);
     pool_free(b->d_na);
     pool_free(b->d_kind);
@@ -384,7 +447,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
 
     /* design tables */
-    std::vector<int32_t> coef_off, pow_off, nb, na, kind;
+    std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, nb, na, kind;
     std::vector<double> coefs, pows;
     size_t ld = 1;
     for (Design &d : bk->designs) {
@@ -393,10 +456,18 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         coefs.insert(coefs.end(), d.a.begin(), d.a.end());
         d.pow_off = (int)pows.size();
         if (d.fast_iir()) {
-            scan_powers(d, kScanT, pows);
+            scan_powers(d, kScanT, kScanLevels, pows);
             const std::vector<double> mine(pows.begin() + d.pow_off, pows.end());
             d.scan_error = scan_probe(d, mine);
+            d.pow2_off = (int)pows.size();
+            scan_powers(d, kScan2T, kScan2Levels, pows);
+            d.levels2 = scan2_levels(&pows[d.pow2_off], d.nb - 1);
+            d.gtab_off = (int)pows.size();
+            scan2_gtable(d, kScan2T, pows);
         }
+        gtab_off.push_back(d.gtab_off);
+        pow2_off.push_back(d.pow2_off);
+        levels2.push_back(d.levels2);
         coef_off.push_back(d.coef_off);
         pow_off.push_back(d.pow_off);
         nb.push_back(d.nb);
@@ -412,26 +483,32 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         const Design &d = bk->designs[bk->design_of[c]];
         std::pair<int, int> key;
         if (d.kind != RTFB_KIND_IIR) key = {kFir, 0};
-        else if (d.fast_iir()) key = {kIirFast, 2 * (d.nb - 1) + (d.scan_safe() ? 1 : 0)};
+        else if (d.fast_iir())
+            key = {kIirFast, 4 * (d.nb - 1) + (d.a[0] == 1.0 ? 2 : 0) + (d.scan_safe() ? 1 : 0)};
         else key = {kIirGeneric, 0};
         auto it = index.find(key);
         if (it == index.end()) {
             Group g;
             g.cls = (GroupClass)key.first;
-            g.order = key.second / 2;
-            g.scan_safe = key.second & 1;
+            g.order = key.second / 4;
+            g.unit_a0 = (key.second & 2) != 0;
+            g.scan_safe = (key.second & 1) != 0;
             it = index.emplace(key, bk->groups.size()).first;
             bk->groups.push_back(g);
         }
         Group &g = bk->groups[it->second];
         g.chans.push_back((int32_t)c);
         g.state_ld = std::max(g.state_ld, d.state_slots());
+        g.levels2_max = std::max(g.levels2_max, d.levels2);
         if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
     }
 
     int rc;
     if ((rc = upload(&bk->d_coef_off, coef_off, device))) return rc;
     if ((rc = upload(&bk->d_pow_off, pow_off, device))) return rc;
+    if ((rc = upload(&bk->d_pow2_off, pow2_off, device))) return rc;
+    if ((rc = upload(&bk->d_levels2, levels2, device))) return rc;
+    if ((rc = upload(&bk->d_gtab_off, gtab_off, device))) return rc;
     if ((rc = upload(&bk->d_nb, nb, device))) return rc;
     if ((rc = upload(&bk->d_na, na, device))) return rc;
     if ((rc = upload(&bk->d_kind, kind, device))) return rc;
@@ -462,6 +539,10 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             std::vector<int32_t> aux(2 * cnt, 0);
             if ((rc = upload(&g.d_aux, aux, device))) return rc;
         }
+        if (g.cls == kIirFast && std::getenv("DSP_AMD_SCAN_STAMPS")) {   /* diagnostics only */
+            std::vector<int32_t> dbg(16 * cnt, 0);
+            if ((rc = upload(&g.d_aux, dbg, device))) return rc;
+        }
         if ((rc = upload(&g.d_fval, fv, device))) return rc;
         if ((rc = upload(&g.d_init, ini, device))) return rc;
     }
@@ -480,10 +561,15 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.state_ld = g.state_ld;
     v.aux = g.d_aux;
     v.kmax = g.kmax;
+    v.unit_a0 = g.unit_a0 ? 1 : 0;
     v.fval = g.d_fval;
     v.init = g.d_init;
     v.coef_off = bk->d_coef_off;
     v.pow_off = bk->d_pow_off;
+    v.pow2_off = bk->d_pow2_off;
+    v.levels2 = bk->d_levels2;
+    v.gtab_off = bk->d_gtab_off;
+    v.levels2_max = g.levels2_max;
     v.nb = bk->d_nb;
     v.na = bk->d_na;
     v.kind = bk->d_kind;
@@ -611,7 +697,7 @@ int dsp_scan_probe(const RTFilterDesign *design, double *rel_error)
     if (d.na) d.a.assign(design->a, design->a + d.na);
     if (!d.fast_iir()) return fail(RTFB_EUNSUPPORTED, "the scan kernel takes IIR designs with na == nb <= 17");
     std::vector<double> pows;
-    scan_powers(d, kScanT, pows);
+    scan_powers(d, kScanT, kScanLevels, pows);
     *rel_error = scan_probe(d, pows);
     return RTFB_OK;
 }
@@ -822,9 +908,26 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
                     (g.chans.size() >= kAutoSeqMinChannels || !g.scan_safe));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
+        else if (g.order <= kScan2MaxOrder && !bank->one_wave_scan) HIP_TRY(launch_iir_scan2(g.order, v, io, s));
         else HIP_TRY(launch_iir_scan(g.order, v, io, s));
     }
     return RTFB_OK;
+}
+
+/* Diagnostics (DSP_AMD_SCAN_STAMPS=1): copy the scan kernel's per-channel phase-cycle sums
+ * (8 uint64 per channel of the first fast-IIR group) to the host. Not declared in the headers. */
+EXPORT int dsp_debug_scan_stamps(RTFilterBank *bank, uint64_t *dst, size_t nwords)
+{
+    if (!bank || !dst) return fail(RTFB_EINVAL, "NULL argument");
+    DeviceScope ds(bank->device);
+    HIP_TRY(hipDeviceSynchronize());
+    for (const Group &g : bank->groups)
+        if (g.cls == kIirFast && g.d_aux) {
+            const size_t have = g.chans.size() * 8;
+            HIP_TRY(hipMemcpy(dst, g.d_aux, std::min(have, nwords) * 8, hipMemcpyDeviceToHost));
+            return RTFB_OK;
+        }
+    return fail(RTFB_EINVAL, "no stamped group (set DSP_AMD_SCAN_STAMPS=1 before creating the bank)");
 }
 
 int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream)

@@ -18,6 +18,10 @@ constexpr int kScanLevels = 6;       /* log2(kWave): Kogge-Stone steps across a 
  * 64 rows x T doubles staged through LDS with one 16-byte pad per row. */
 constexpr int kSeqT = 32;            /* sequential kernel: rows are channels          */
 constexpr int kScanT = 64;           /* scan kernel: rows are consecutive time chunks */
+constexpr int kScan2T = 32;          /* two-wave scan kernel: samples per lane                */
+constexpr int kScan2Rows = 128;      /* ... lanes (= time chunks) per segment                 */
+constexpr int kScan2Levels = 7;      /* log2(kScan2Rows)                                      */
+constexpr int kScan2MaxOrder = 8;    /* orders served by the two-wave kernel (LDS budget)     */
 constexpr int kFirT = 32;            /* FIR kernel: outputs per lane                  */
 constexpr int kFirR = 8;             /* FIR kernel: outputs accumulated together      */
 constexpr int kFirSeg = kWave * kFirT;   /* outputs per wavefront                    */
@@ -37,10 +41,16 @@ struct GroupView {
                                  sample t0 (1 if sample 0 went to stable_init) and the stream
                                  index of the block's sample 0 while a partial_init ramp runs */
     int32_t        kmax;      /* FIR only: largest tap count in the group                 */
+    int32_t        unit_a0;   /* IIR fast groups: every design has a[0] == 1.0 exactly    */
     double        *fval;      /* RTFilter.filtered_value per g                            */
     int32_t       *init;      /* RTFilter.initialized per g                               */
     const int32_t *coef_off;  /* per design: offset of b[0] in coefs (a follows b)        */
     const int32_t *pow_off;   /* per design: offset of the kScanLevels N x N matrices     */
+    const int32_t *pow2_off;  /* per design: offset of the kScan2Levels matrices A^(32 2^k) */
+    const int32_t *levels2;   /* per design: combine levels that still matter (decay cut)  */
+    const int32_t *gtab_off;  /* per design: offset in pows of G[n][i] = (A^(31-n) B)_i, n < 32,
+                                 followed by Gc[i] = (sum_m A^m e_{N-1})_i                  */
+    int32_t        levels2_max;   /* largest levels2 in the group                          */
     const int32_t *nb;        /* per design                                               */
     const int32_t *na;        /* per design                                               */
     const int32_t *kind;      /* per design: RTFB_KIND_*                                  */
@@ -60,6 +70,7 @@ struct BlockIO {
 /* launchers (kernels.hip).  Each returns the hipError_t of the launch. */
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_iir_scan2(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_reset(const GroupView &g, hipStream_t s);

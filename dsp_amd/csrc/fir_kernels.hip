@@ -112,7 +112,7 @@ fir_main_kernel(GroupView g, BlockIO io, int seg0)
         const long long idx = in_base + e;
         lds[skew(e)] = (idx >= 0 && idx < n) ? x[idx] : 0.0;
     }
-    __syncthreads();
+    wave_sync();
 
     const double b0 = b[0];
     double y[T];
@@ -171,12 +171,12 @@ fir_main_kernel(GroupView g, BlockIO io, int seg0)
             y[blk * R + r] = v;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     /* park outputs in LDS (same skew), then store coalesced */
 #pragma unroll
     for (int j = 0; j < T; ++j) lds[skew(lane * T + j)] = y[j];
-    __syncthreads();
+    wave_sync();
     for (int e = lane; e < S; e += kWave) {
         const long long m = seg_base + e;
         if (m >= t0 && m < n) out[m] = lds[skew(e)];

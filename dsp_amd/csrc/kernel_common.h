@@ -23,6 +23,14 @@ __device__ __forceinline__ cint_p as_const(const int32_t *p)
     return (cint_p)(uintptr_t)p;
 }
 
+/* Ordering point between LDS phases of a ONE-WAVEFRONT workgroup.  A wave's LDS
+ * instructions execute in issue order, so a ds_read issued after a ds_write
+ * sees its data, other lanes' included; only the compiler has to be kept from
+ * moving accesses across.  __syncthreads() must not be used here: it lowers to
+ * s_waitcnt vmcnt(0) + s_barrier and would drain the global prefetch and the
+ * output stores that these kernels keep in flight across phases. */
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 __device__ __forceinline__ int group_channel(const GroupView &g, int idx)
 {
     return g.chan ? g.chan[idx] : g.chan0 + idx;

@@ -18,6 +18,7 @@
  */
 #include "dsp_internal.h"
 #include "kernel_common.h"
+#include "iir_steps.h"
 
 namespace dsp {
 
@@ -32,68 +33,6 @@ struct Tile {
 
 /* ------------------------------------------------------------------------ */
 /* arithmetic leaves                                                         */
-
-/* One RTIIRFilter_update (ref: src/RTFilter.c:396-439) for na == nb == N+1, in
- * the reference's exact operation order:
- *   y    = ((x*b0) + s0) / a0
- *   t    = (0.0 + b[i+1]*x) - a[i+1]*y ;  s[i] = s[i+1] + t      i = 0..N-1
- * The literal `0.0 +` is kept: it turns a -0.0 product into +0.0 as the
- * reference's `state_value = 0.0; state_value += ...` does.  x / 1.0 == x
- * exactly, so the divide is skipped when a0 == 1 (every reference design sets
- * a0 = 1: src/RTFilter.c:1156,1255,1352). */
-template <int N>
-__device__ __forceinline__ double iir_step_ref(double x, double (&s)[N + 1],
-                                               const double (&b)[N + 1],
-                                               const double (&a)[N + 1])
-{
-    double t = x * b[0];
-    t = t + s[0];
-    double y = t;
-    if (a[0] != 1.0) y = t / a[0];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double u = 0.0 + b[i + 1] * x;
-        u = u - a[i + 1] * y;
-        s[i] = s[i + 1] + u;
-    }
-    return y;
-}
-
-/* Same recurrence with explicit FMAs: used only where the result feeds the
- * prefix combine (zero-state pass), never for an output sample. */
-template <int N>
-__device__ __forceinline__ void iir_step_fused(double x, double (&s)[N + 1],
-                                               const double (&b)[N + 1],
-                                               const double (&a)[N + 1])
-{
-    double y = __builtin_fma(x, b[0], s[0]);
-    if (a[0] != 1.0) y = y / a[0];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        s[i] = __builtin_fma(-a[i + 1], y, __builtin_fma(b[i + 1], x, s[i + 1]));
-}
-
-/* RTIIRFilter_stable_init (ref: src/RTFilter.c:441-475), na == nb == N+1 >= 2. */
-template <int N>
-__device__ __forceinline__ double iir_seed_ref(double x, double (&s)[N + 1],
-                                               const double (&b)[N + 1],
-                                               const double (&a)[N + 1])
-{
-    double num = 0.0 + b[0];
-    num = num + b[1];
-    double den = 0.0 + a[0];
-    den = den + a[1];
-    const double d = num / den;
-    double run = 0.0;
-    s[N] = 0.0;
-#pragma unroll
-    for (int i = N; i >= 1; --i) {
-        run = run + b[i];
-        run = run - a[i] * d;
-        s[i - 1] = run * x;
-    }
-    return d * x;
-}
 
 __device__ __forceinline__ double shfl_up_f64(double v, int delta)
 {
@@ -110,7 +49,7 @@ __device__ __forceinline__ double shfl_f64(double v, int src)
 /* A wavefront owns 64 channels and walks time in tiles of T samples; state   */
 /* and coefficients stay in registers for the whole block.                    */
 
-template <int N, int T>
+template <int N, int T, bool kUnitA0>
 __global__ void __launch_bounds__(kWave)
 iir_seq_kernel(GroupView g, BlockIO io)
 {
@@ -164,22 +103,22 @@ iir_seq_kernel(GroupView g, BlockIO io)
             }
             *reinterpret_cast<d2 *>(smem + r * TG::kRowBytes + q * 16) = v;
         }
-        __syncthreads();
+        wave_sync();
 
         /* walk my row in the reference's order */
         char *row = smem + lane * TG::kRowBytes;
         for (int k = 0; k < cnt; k += 2) {
             d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
             if (ini != 0) { y = iir_seed_ref<N>(xv.x, s, b, a); ini = 0; }
-            else y = iir_step_ref<N>(xv.x, s, b, a);
+            else y = iir_step_ref<N, kUnitA0>(xv.x, s, b, a);
             xv.x = y;
             if (k + 1 < cnt) {
-                y = iir_step_ref<N>(xv.y, s, b, a);
+                y = iir_step_ref<N, kUnitA0>(xv.y, s, b, a);
                 xv.y = y;
             }
             *reinterpret_cast<d2 *>(row + k * 8) = xv;
         }
-        __syncthreads();
+        wave_sync();
 
         /* stage out */
 #pragma unroll 4
@@ -201,7 +140,7 @@ iir_seq_kernel(GroupView g, BlockIO io)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 
     if (live) {
@@ -223,20 +162,29 @@ iir_seq_kernel(GroupView g, BlockIO io)
 /*   combine Kogge-Stone prefix over lanes of the affine maps s -> M s + v,   */
 /*           M = A^T (A = companion matrix of the homogeneous recurrence);    */
 /*           step k uses the precomputed power A^(T*2^k): 6 N x N mat-vecs    */
-/*   pass 2  every lane re-runs its T samples from its TRUE start state in    */
-/*           the reference's operation order and writes y in place            */
+/*   pass 2  every lane re-runs its T samples from its TRUE start state and   */
+/*           writes y in place                                                */
 /* The carried state of the next segment is lane 63's state after pass 2.     */
 /* x is read from HBM once and y written once; both passes run out of LDS.    */
-/* Pass 2 being the reference's own arithmetic, an output differs from the    */
-/* reference only through the rounding of its lane's start state, which the   */
-/* filter's own decay damps.                                                  */
+/* Both passes use fused multiply-adds (2N+1 per sample): the kernel is       */
+/* re-associated anyway, its bar is 1e-12 relative to peak, and the bank only */
+/* routes designs here whose conditioning probe passed (bank.hip).            */
 
-template <int N, int T, bool kGeneral>
+template <int N, int T, bool kUnitA0, bool kGeneral, bool kStamp>
 __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, bool do_seed,
                                              const double (&b)[N + 1], const double (&a)[N + 1],
                                              cdouble_p pw,
-                                             double (&carry)[N + 1], double &ylast)
+                                             double (&carry)[N + 1], double &ylast,
+                                             unsigned long long (&acc_t)[6],
+                                             unsigned long long &t_prev)
 {
+    auto stamp = [&](int slot) {
+        if (kStamp) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            acc_t[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
     using TG = Tile<T>;
     char *row = smem + lane * TG::kRowBytes;
 
@@ -259,36 +207,45 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
     if (kGeneral) {
         int k = 0;
         if (seed_here) { (void)iir_seed_ref<N>(*reinterpret_cast<double *>(row), v, b, a); k = 1; }
-        for (; k < cnt; ++k) iir_step_fused<N>(*reinterpret_cast<double *>(row + k * 8), v, b, a);
+        for (; k < cnt; ++k) (void)iir_step_fused<N, kUnitA0>(*reinterpret_cast<double *>(row + k * 8), v, b, a);
     } else {
-#pragma unroll 2
-        for (int k = 0; k < T; k += 2) {
-            const d2 xv = *reinterpret_cast<const d2 *>(row + k * 8);
-            iir_step_fused<N>(xv.x, v, b, a);
-            iir_step_fused<N>(xv.y, v, b, a);
+        d2 cur0 = *reinterpret_cast<const d2 *>(row);
+        d2 cur1 = *reinterpret_cast<const d2 *>(row + 16);
+#pragma unroll 1
+        for (int k = 0; k < T; k += 4) {
+            const int kn = (k + 4 < T) ? k + 4 : k;         /* last round re-reads itself */
+            const d2 nxt0 = *reinterpret_cast<const d2 *>(row + kn * 8);
+            const d2 nxt1 = *reinterpret_cast<const d2 *>(row + kn * 8 + 16);
+            iir_step_fused<N, kUnitA0>(cur0.x, v, b, a);
+            iir_step_fused<N, kUnitA0>(cur0.y, v, b, a);
+            iir_step_fused<N, kUnitA0>(cur1.x, v, b, a);
+            iir_step_fused<N, kUnitA0>(cur1.y, v, b, a);
+            cur0 = nxt0;
+            cur1 = nxt1;
         }
     }
 
+    stamp(2);
     /* ---- prefix combine across lanes: v_j <- end state after lane j ---- */
 #pragma unroll
     for (int lvl = 0; lvl < kScanLevels; ++lvl) {
         const int d = 1 << lvl;
         double u[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double up = shfl_up_f64(v[i], d);
-            u[i] = (lane >= d) ? up : 0.0;
-        }
+        for (int i = 0; i < N; ++i) u[i] = shfl_up_f64(v[i], d);
         cdouble_p M = pw + lvl * N * N;
+        if (lane >= d) {                       /* lanes below d keep their value (exec-masked) */
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double acc = v[i];
+            for (int i = 0; i < N; ++i) {
+                double acc = v[i];
 #pragma unroll
-            for (int j = 0; j < N; ++j) acc = __builtin_fma(M[i * N + j], u[j], acc);
-            v[i] = acc;
+                for (int j = 0; j < N; ++j) acc = __builtin_fma(M[i * N + j], u[j], acc);
+                v[i] = acc;
+            }
         }
     }
 
+    stamp(3);
     /* ---- pass 2: true start state = end state of the lane before ---- */
     double s[N + 1];
 #pragma unroll
@@ -306,26 +263,39 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
             k = 1;
         }
         for (; k < cnt; ++k) {
-            y = iir_step_ref<N>(*reinterpret_cast<double *>(row + k * 8), s, b, a);
+            y = iir_step_fused<N, kUnitA0>(*reinterpret_cast<double *>(row + k * 8), s, b, a);
             *reinterpret_cast<double *>(row + k * 8) = y;
         }
     } else {
-#pragma unroll 2
-        for (int k = 0; k < T; k += 2) {
-            d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
-            xv.x = iir_step_ref<N>(xv.x, s, b, a);
-            xv.y = y = iir_step_ref<N>(xv.y, s, b, a);
-            *reinterpret_cast<d2 *>(row + k * 8) = xv;
+        d2 cur0 = *reinterpret_cast<const d2 *>(row);
+        d2 cur1 = *reinterpret_cast<const d2 *>(row + 16);
+#pragma unroll 1
+        for (int k = 0; k < T; k += 4) {
+            const int kn = (k + 4 < T) ? k + 4 : k;
+            const d2 nxt0 = *reinterpret_cast<const d2 *>(row + kn * 8);
+            const d2 nxt1 = *reinterpret_cast<const d2 *>(row + kn * 8 + 16);
+            cur0.x = iir_step_fused<N, kUnitA0>(cur0.x, s, b, a);
+            cur0.y = iir_step_fused<N, kUnitA0>(cur0.y, s, b, a);
+            cur1.x = iir_step_fused<N, kUnitA0>(cur1.x, s, b, a);
+            cur1.y = y = iir_step_fused<N, kUnitA0>(cur1.y, s, b, a);
+            *reinterpret_cast<d2 *>(row + k * 8) = cur0;
+            *reinterpret_cast<d2 *>(row + k * 8 + 16) = cur1;
+            cur0 = nxt0;
+            cur1 = nxt1;
         }
     }
 
+    stamp(4);
     /* carry out = state of the lane that consumed the segment's last sample */
 #pragma unroll
     for (int i = 0; i <= N; ++i) carry[i] = shfl_f64(s[i], jlast);
     ylast = shfl_f64(y, jlast);
 }
 
-template <int N, int T>
+/* kStamp: diagnostic instantiation only (never the shipped path).  Per-phase
+ * s_memtime deltas are summed per wavefront and written to g.aux (as 8
+ * uint64 per channel): park, prefetch issue, pass 1, combine, pass 2, store. */
+template <int N, int T, bool kUnitA0, bool kStamp = false>
 __global__ void __launch_bounds__(kWave)
 iir_scan_kernel(GroupView g, BlockIO io)
 {
@@ -378,7 +348,18 @@ iir_scan_kernel(GroupView g, BlockIO io)
         }
     };
 
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int slot) {
+        if (kStamp) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            acc_t[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
+
     fetch(0);
+    if (kStamp) t_prev = __builtin_readcyclecounter();
     for (size_t base = 0; base < n; base += kSeg) {
         const size_t left = n - base;
         const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
@@ -390,15 +371,19 @@ iir_scan_kernel(GroupView g, BlockIO io)
             *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
                                     (p % TG::kPiecesPerRow) * 16) = pre[i];
         }
-        __syncthreads();
+        wave_sync();
+        stamp(0);
         if (base + kSeg < n) fetch(base + kSeg);     /* next segment's loads fly during compute */
+        stamp(1);
 
         if (seg_len == kSeg && !need_seed)
-            scan_segment<N, T, false>(smem, lane, seg_len, false, b, a, pw, carry, ylast);
+            scan_segment<N, T, kUnitA0, false, kStamp>(smem, lane, seg_len, false, b, a, pw, carry,
+                                                       ylast, acc_t, t_prev);
         else
-            scan_segment<N, T, true>(smem, lane, seg_len, need_seed, b, a, pw, carry, ylast);
+            scan_segment<N, T, kUnitA0, true, kStamp>(smem, lane, seg_len, need_seed, b, a, pw, carry,
+                                                      ylast, acc_t, t_prev);
         need_seed = false;
-        __syncthreads();
+        wave_sync();
 
         if (seg_len == kSeg && io.aligned16) {
 #pragma unroll 8
@@ -418,7 +403,8 @@ iir_scan_kernel(GroupView g, BlockIO io)
                 if (e + 1 < seg_len) dst[base + e + 1] = v.y;
             }
         }
-        __syncthreads();
+        wave_sync();
+        stamp(5);
     }
 
     if (lane == 0) {
@@ -427,6 +413,10 @@ iir_scan_kernel(GroupView g, BlockIO io)
         for (int i = 0; i <= N; ++i) st[i] = carry[i];
         g.fval[gi] = ylast;
         g.init[gi] = 0;
+        if (kStamp) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.aux) + (size_t)gi * 8;
+            for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
+        }
     }
 }
 
@@ -524,16 +514,29 @@ template <int N>
 static hipError_t launch_seq_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
     const int blocks = (g.count + kWave - 1) / kWave;
-    hipLaunchKernelGGL((iir_seq_kernel<N, kSeqT>), dim3(blocks), dim3(kWave),
-                       Tile<kSeqT>::kBytes, s, g, io);
+    if (g.unit_a0)
+        hipLaunchKernelGGL((iir_seq_kernel<N, kSeqT, true>), dim3(blocks), dim3(kWave),
+                           Tile<kSeqT>::kBytes, s, g, io);
+    else
+        hipLaunchKernelGGL((iir_seq_kernel<N, kSeqT, false>), dim3(blocks), dim3(kWave),
+                           Tile<kSeqT>::kBytes, s, g, io);
     return hipGetLastError();
 }
 
 template <int N>
 static hipError_t launch_scan_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
-    hipLaunchKernelGGL((iir_scan_kernel<N, kScanT>), dim3(g.count), dim3(kWave),
-                       Tile<kScanT>::kBytes, s, g, io);
+    if (N == 8 && g.unit_a0 && g.aux) {          /* diagnostic build with phase stamps */
+        hipLaunchKernelGGL((iir_scan_kernel<8, kScanT, true, true>), dim3(g.count), dim3(kWave),
+                           Tile<kScanT>::kBytes, s, g, io);
+        return hipGetLastError();
+    }
+    if (g.unit_a0)
+        hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
+                           Tile<kScanT>::kBytes, s, g, io);
+    else
+        hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, false>), dim3(g.count), dim3(kWave),
+                           Tile<kScanT>::kBytes, s, g, io);
     return hipGetLastError();
 }
 
