@@ -43,7 +43,7 @@ def cpu_baseline(b, a):
     from oracle import ref
     from tests import util
     threads = max(1, min(16, os.cpu_count() or 1))
-    per_thread = max(1, CHANNELS // threads // 4)     # bounded sample: a quarter of one stream pass
+    per_thread = max(1, CHANNELS // threads)          # bounded sample: one pass of the 1024 streams
     kind = "reference" if ref.available() else "port"
     xs = [util.synth(SEED, t, 0, STREAM) for t in range(threads)]
 
@@ -54,7 +54,6 @@ def cpu_baseline(b, a):
             else:
                 orc.iir(b, a).updaten(xs[t])
 
-    work(0) if per_thread == 1 else None
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(work, range(threads)))
@@ -63,6 +62,18 @@ def cpu_baseline(b, a):
     return dict(value=nsamp / dt / 1e6, unit="Msamples/s", cores=threads, kind=kind,
                 sample="%d channels x 2^20 samples of config 2 (%s), RTFilter_updaten per channel, "
                        "%d host threads, %.1f s" % (threads * per_thread, DESIGN, threads, dt))
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes).  None if
+    the profile file is absent; bench.py itself does not run the profiler."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -149,7 +160,8 @@ def main():
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,
                          "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
         }
         if world == 1 and not args.no_cpu:
