@@ -145,6 +145,27 @@ def main():
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in events]
     kern_avg_s = float(np.mean(kern_ms)) / 1e3
 
+    # Streaming-copy ceiling of this device for the same shape (1024 rows x one 64K block, read + write,
+    # no arithmetic): what a 16 B/sample kernel could reach at best here.  Untimed extra, rank 0 only.
+    copy_gbs = None
+    if rank == 0:
+        import ctypes as C
+        from dsp_amd.cdsp import dspdll
+        cts = []
+        for k in range(12):
+            j = k % NBLOCKS
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = dspdll.dsp_copy_rows(C.c_void_p(y.data_ptr() + j * BLOCK * 8), STREAM,
+                                      C.c_void_p(x.data_ptr() + j * BLOCK * 8), STREAM, CHANNELS, BLOCK,
+                                      256, 8192, C.c_void_p(stream.cuda_stream))
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if rc == 0 and k >= 4:
+                cts.append(e0.elapsed_time(e1))
+        if cts:
+            copy_gbs = CHANNELS * BLOCK * BYTES_PER_SAMPLE / (float(np.median(cts)) / 1e3) / 1e9
+
     if rank == 0:
         samples_per_step = CHANNELS * BLOCK
         value = world * samples_per_step * args.steps / elapsed / 1e6
@@ -162,6 +183,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,
+                         "copy_ceiling_measured": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
         }
         if world == 1 and not args.no_cpu:

@@ -157,6 +157,7 @@ _proto("dsp_pool_trim", c_int, [c_int])
 _proto("dsp_pool_bytes_in_use", c_size_t, [c_int])
 _proto("dsp_pool_bytes_cached", c_size_t, [c_int])
 _proto("dsp_synth_fill", c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_uint64, c_uint64, c_uint64, c_void_p])
+_proto("dsp_copy_rows", c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_int, c_void_p])
 _proto("dsp_device_count", c_int, [])
 _proto("dsp_memcpy_h2d", c_int, [c_void_p, c_void_p, c_size_t, c_int])
 _proto("dsp_memcpy_d2h", c_int, [c_void_p, c_void_p, c_size_t, c_int])

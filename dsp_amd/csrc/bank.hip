@@ -189,6 +189,7 @@ struct Design {
     int pow2_off = 0;
     int levels2 = 0;
     int gtab_off = 0;
+    int ttab_off = -1;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
     bool scan_safe() const;
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
@@ -228,14 +229,15 @@ struct RTFilterBank {
     int device = 0;
     size_t nch = 0;
     int mode = RTFB_MODE_AUTO;
-    bool one_wave_scan = std::getenv("DSP_AMD_ONE_WAVE_SCAN") != nullptr;   /* A/B switch for profiling */
+    /* A/B switch for profiling: DSP_AMD_SCAN_VARIANT = 0 pipelined (default), 1 two-wave, 2 one-wave */
+    int scan_variant = std::getenv("DSP_AMD_SCAN_VARIANT") ? std::atoi(std::getenv("DSP_AMD_SCAN_VARIANT")) : 0;
     std::vector<Design> designs;
     std::vector<int32_t> design_of;     /* per channel */
     std::vector<Group> groups;
     std::vector<RTFilter *> host_filters;   /* from_filters only */
     size_t state_ld = 1;                /* uniform ld of the get/set_state API */
     /* device tables shared by all groups */
-    int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_pow2_off = nullptr, *d_levels2 = nullptr, *d_gtab_off = nullptr,
+    int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_pow2_off = nullptr, *d_levels2 = nullptr, *d_gtab_off = nullptr, *d_ttab_off = nullptr,
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
 };
@@ -305,11 +307,38 @@ void scan2_gtable(const Design &d, int T, std::vector<double> &out)
     for (int i = 0; i < N; ++i) out.push_back((double)acc[i]);
 }
 
+/* Row propagators of the pipelined kernel: A^(32 j), j = 0..63, row-major (long double products). */
+void pipe_ttable(const Design &d, int T, std::vector<double> &out)
+{
+    const int N = d.nb - 1;
+    typedef std::vector<long double> Mat;
+    auto mul = [N](const Mat &p, const Mat &q) {
+        Mat r((size_t)N * N, 0.0L);
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < N; ++k)
+                for (int j = 0; j < N; ++j) r[(size_t)i * N + j] += p[(size_t)i * N + k] * q[(size_t)k * N + j];
+        return r;
+    };
+    Mat A((size_t)N * N, 0.0L), P((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i) {
+        A[(size_t)i * N] = -(long double)d.a[i + 1] / (long double)d.a[0];
+        if (i + 1 < N) A[(size_t)i * N + i + 1] += 1.0L;
+        P[(size_t)i * N + i] = 1.0L;
+    }
+    Mat AT = A;
+    for (int t = 1; t < T; t <<= 1) AT = mul(AT, AT);
+    for (int j = 0; j < kWave; ++j) {
+        for (size_t e = 0; e < P.size(); ++e) out.push_back((double)P[e]);
+        P = mul(AT, P);
+    }
+}
+
 /* Combine levels of the two-wave scan kernel that still matter for a design:
  * level k applies A^(32*2^k); once every entry of that power (and of all
  * higher ones) is below 2^-75 its contribution is more than 2^-20 below one ulp
  * of the state it is added to, and the kernel skips it. */
 constexpr double kScan2Negligible = 0x1.0p-75;
+constexpr size_t kMaxPipeDesigns = 1024;     /* 64 propagators of N x N doubles per design */
 
 int scan2_levels(const double *pw, int N)
 {
@@ -429,6 +458,7 @@ void free_bank_device(RTFilterBank *b)
     pool_free(b->d_pow2_off);
     pool_free(b->d_levels2);
     pool_free(b->d_gtab_off);
+    pool_free(b->d_ttab_off);
     pool_free(b->d_nb);
     pool_free(b->d_na);
     pool_free(b->d_kind);
@@ -447,7 +477,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
 
     /* design tables */
-    std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, nb, na, kind;
+    std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, nb, na, kind;
     std::vector<double> coefs, pows;
     size_t ld = 1;
     for (Design &d : bk->designs) {
@@ -464,8 +494,13 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             d.levels2 = scan2_levels(&pows[d.pow2_off], d.nb - 1);
             d.gtab_off = (int)pows.size();
             scan2_gtable(d, kScan2T, pows);
+            if (d.nb - 1 <= kScan2MaxOrder && bk->designs.size() <= kMaxPipeDesigns) {
+                d.ttab_off = (int)pows.size();
+                pipe_ttable(d, kScan2T, pows);
+            }
         }
         gtab_off.push_back(d.gtab_off);
+        ttab_off.push_back(d.ttab_off);
         pow2_off.push_back(d.pow2_off);
         levels2.push_back(d.levels2);
         coef_off.push_back(d.coef_off);
@@ -509,6 +544,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if ((rc = upload(&bk->d_pow2_off, pow2_off, device))) return rc;
     if ((rc = upload(&bk->d_levels2, levels2, device))) return rc;
     if ((rc = upload(&bk->d_gtab_off, gtab_off, device))) return rc;
+    if ((rc = upload(&bk->d_ttab_off, ttab_off, device))) return rc;
     if ((rc = upload(&bk->d_nb, nb, device))) return rc;
     if ((rc = upload(&bk->d_na, na, device))) return rc;
     if ((rc = upload(&bk->d_kind, kind, device))) return rc;
@@ -569,6 +605,7 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.pow2_off = bk->d_pow2_off;
     v.levels2 = bk->d_levels2;
     v.gtab_off = bk->d_gtab_off;
+    v.ttab_off = bk->d_ttab_off;
     v.levels2_max = g.levels2_max;
     v.nb = bk->d_nb;
     v.na = bk->d_na;
@@ -908,9 +945,26 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
                     (g.chans.size() >= kAutoSeqMinChannels || !g.scan_safe));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
-        else if (g.order <= kScan2MaxOrder && !bank->one_wave_scan) HIP_TRY(launch_iir_scan2(g.order, v, io, s));
+        else if (g.order <= kScan2MaxOrder && bank->scan_variant == 0 &&
+                 bank->designs.size() <= kMaxPipeDesigns)
+            HIP_TRY(launch_iir_pipe(g.order, v, io, s));
+        else if (g.order <= kScan2MaxOrder && bank->scan_variant <= 1) HIP_TRY(launch_iir_scan2(g.order, v, io, s));
         else HIP_TRY(launch_iir_scan(g.order, v, io, s));
     }
+    return RTFB_OK;
+}
+
+int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch, size_t n,
+                  int threads, int seg, void *hip_stream)
+{
+    if (!out || !in) return fail(RTFB_EINVAL, "dsp_copy_rows: NULL argument");
+    if ((threads != 64 && threads != 128 && threads != 256) || seg <= 0 || seg % (2 * threads) ||
+        seg / 2 / threads > 16 || n % (size_t)seg)
+        return fail(RTFB_EINVAL, "dsp_copy_rows: threads in {64,128,256}, seg a multiple of 2*threads, "
+                                 "at most 32*threads, dividing n");
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16) || ld_in % 2 || ld_out % 2)
+        return fail(RTFB_EINVAL, "dsp_copy_rows: needs 16-byte aligned rows");
+    HIP_TRY(launch_copy_rows(out, ld_out, in, ld_in, nch, n, threads, seg, static_cast<hipStream_t>(hip_stream)));
     return RTFB_OK;
 }
 

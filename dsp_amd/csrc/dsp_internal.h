@@ -48,6 +48,8 @@ struct GroupView {
     const int32_t *pow_off;   /* per design: offset of the kScanLevels N x N matrices     */
     const int32_t *pow2_off;  /* per design: offset of the kScan2Levels matrices A^(32 2^k) */
     const int32_t *levels2;   /* per design: combine levels that still matter (decay cut)  */
+    const int32_t *ttab_off;  /* per design: offset in pows of the 64 row propagators A^(32 j),
+                                 j = 0..63, row-major (pipelined kernel); -1 if not built   */
     const int32_t *gtab_off;  /* per design: offset in pows of G[n][i] = (A^(31-n) B)_i, n < 32,
                                  followed by Gc[i] = (sum_m A^m e_{N-1})_i                  */
     int32_t        levels2_max;   /* largest levels2 in the group                          */
@@ -71,12 +73,15 @@ struct BlockIO {
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan2(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_iir_pipe(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_reset(const GroupView &g, hipStream_t s);
 hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
                         uint64_t chan0, uint64_t n0, hipStream_t s);
 
+hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
+                            size_t n, int threads, int seg, hipStream_t s);
 bool iir_scan_supported(int order);
 
 }  // namespace dsp

@@ -507,6 +507,51 @@ __global__ void synth_kernel(double *dst, size_t ld, size_t nch, size_t n, uint6
     }
 }
 
+/* Diagnostic: the scan kernels' memory access pattern with no arithmetic -- one workgroup per
+ * channel walks its row in `seg`-sample pieces, two pieces of loads in flight, coalesced 16-byte
+ * loads and stores.  Gives the HBM ceiling OF THIS PATTERN to read roofline fractions against. */
+template <int kThreads>
+__global__ void __launch_bounds__(kThreads)
+copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, size_t n, int seg)
+{
+    const double *src = in + (size_t)blockIdx.x * ld_in;
+    double *dst = out + (size_t)blockIdx.x * ld_out;
+    const int per = seg / 2 / kThreads;              /* 16-byte pieces per thread per segment (<= 16) */
+    d2 buf0[16], buf1[16];
+    auto load = [&](size_t base, d2(&buf)[16]) {
+        if (base >= n) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < per) buf[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kThreads + threadIdx.x));
+    };
+    auto store = [&](size_t base, d2(&buf)[16]) {
+        if (base >= n) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < per) *reinterpret_cast<d2 *>(dst + base + 2 * (i * kThreads + threadIdx.x)) = buf[i];
+    };
+    load(0, buf0);
+    load(seg, buf1);
+    for (size_t base = 0; base < n; base += 2 * (size_t)seg) {
+        store(base, buf0);
+        load(base + 2 * (size_t)seg, buf0);
+        store(base + seg, buf1);
+        load(base + 3 * (size_t)seg, buf1);
+    }
+}
+
+hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
+                            size_t n, int threads, int seg, hipStream_t s)
+{
+    if (threads == 64)
+        hipLaunchKernelGGL(copy_rows_kernel<64>, dim3((unsigned)nch), dim3(64), 0, s, out, ld_out, in, ld_in, n, seg);
+    else if (threads == 128)
+        hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg);
+    else
+        hipLaunchKernelGGL(copy_rows_kernel<256>, dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------ */
 /* launchers                                                                  */
 

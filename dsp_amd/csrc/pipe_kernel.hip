@@ -1,0 +1,351 @@
+/*
+ * pipe_kernel.hip -- the pipelined time-parallel IIR kernel (gfx950), orders <= 8.
+ *
+ * Same mathematics as the other scan kernels (a chunk of T samples is the affine
+ * map s_end = A^T s_start + v; see kernels.hip / scan2_kernel.hip), arranged so
+ * that ONLY the part that truly depends on the previous segment sits on the
+ * segment-to-segment critical path.  Measured on MI355X, the two-wave kernel is
+ * neither HBM- nor VALU-bound: its phases run back to back per channel and a CU
+ * only ever holds 4 channels of a 1024-channel bank (profiles/r1_scan_phases.txt).
+ *
+ * A channel is served by a 2-wave workgroup with FIXED ROLES, software-pipelined
+ * one 2048-sample segment apart (64 rows x 32 samples, two LDS tiles):
+ *
+ *   FRONT wave, segment i      carry-independent work
+ *       park prefetched x(i) in LDS, keep two further segments' loads in flight,
+ *       zero-state row vectors  v_j = sum_n G[n] x[n]          (table G = A^(31-n) B)
+ *       Kogge-Stone prefix over the 64 rows with ZERO carry-in (levels that have
+ *       decayed below 2^-75 skipped), publish P_j = state row j would start from
+ *       if the segment started from zero
+ *   BACK wave, segment i-1     the critical path
+ *       s_j = P_j + A^(32 j) carry    one N x N mat-vec per lane, the lane's own matrix
+ *                                     A^(32 j) held in registers for the whole launch
+ *       run the 32 samples from s_j (fused recurrence), write y in place,
+ *       carry = last row's state, store the segment coalesced
+ *
+ * Two workgroup barriers per segment keep the roles one segment apart; all other
+ * synchronisation is implicit in the in-order LDS queue of each wave.
+ * HBM traffic: 16 B/sample (x once in, y once out).  Not bit-exact (re-associated);
+ * bar 1e-12 relative to peak, designs are admitted by the host's conditioning probe.
+ */
+#include "dsp_internal.h"
+#include "kernel_common.h"
+#include "iir_steps.h"
+
+namespace dsp {
+
+namespace {
+
+constexpr int PT = kScan2T;                 /* 32 samples per row */
+constexpr int kPRows = kWave;               /* 64 rows per segment */
+constexpr int kPSeg = PT * kPRows;          /* 2048 samples */
+constexpr int kPTile = kPRows * PT * 8;     /* 16384 bytes */
+constexpr int kPPieces = kPSeg / 2 / kWave; /* 16 pieces of 16 B per lane */
+constexpr int kPLevels = 6;                 /* log2(64) */
+
+}  // namespace
+
+template <int N, bool kUnitA0>
+__global__ void __launch_bounds__(2 * kWave, 2)
+iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile0 = smem;
+    char *tile1 = smem + kPTile;
+    double *mats = reinterpret_cast<double *>(smem + 2 * kPTile);    /* lds_levels x N x N, column-major */
+    double *pbuf = mats + lds_levels * N * N;                         /* 64 x N start states */
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const bool front = tid < kWave;
+    const int gi = blockIdx.x;
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+    int nlev = as_const(g.levels2)[dsn];
+    if (nlev > kPLevels) nlev = kPLevels;
+
+    const size_t n = io.n;
+    const int nseg = (int)((n + kPSeg - 1) / kPSeg);
+    const double *src = io.in + (size_t)chan * io.ld_in;
+    double *dst = io.out + (size_t)chan * io.ld_out;
+    const bool seed_stream = g.init[gi] != 0;
+
+    /* matrix powers of this design -> LDS, transposed to column-major */
+    {
+        const double *pw = g.pows + g.pow2_off[dsn];
+        for (int e = tid; e < nlev * N * N; e += 2 * kWave) {
+            const int lvl = e / (N * N), r = e % (N * N);
+            mats[lvl * N * N + (r % N) * N + (r / N)] = pw[e];
+        }
+        if (tid < N) pbuf[tid] = 0.0;                       /* row 0 never receives a prefix */
+    }
+
+    /* staging geometry (both roles): piece p = i*64 + lane -> row i*4 + (lane>>4), column lane&15 */
+    const int st_r = lane >> 4;
+    int st_addr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+        st_addr[v] = st_r * (PT * 8) + (((lane & 15) ^ (v * 4 + st_r)) << 4);
+    const int rx = (lane & 15) << 4;
+
+    double b[N + 1], a[N + 1];
+    {
+        cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            b[i] = cf[i];
+            a[i] = cf[N + 1 + i];
+        }
+    }
+    const double tail0 = g.state[(size_t)gi * g.state_ld + N];   /* s[N]: read, never written */
+
+    if (front) {
+        /* =============================== FRONT =============================== */
+        cdouble_p gtab = as_const(g.pows) + as_const(g.gtab_off)[dsn];
+        d2 pre0[kPPieces], pre1[kPPieces];
+
+        auto fetch = [&](int seg, d2(&pre)[kPPieces]) {
+            const size_t base = (size_t)seg * kPSeg;
+            if (base >= n) return;
+            const size_t left = n - base;
+            const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
+            if (seg_len == kPSeg && io.aligned16) {
+#pragma unroll
+                for (int i = 0; i < kPPieces; ++i)
+                    pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+            } else {
+#pragma unroll
+                for (int i = 0; i < kPPieces; ++i) {
+                    const int e = 2 * (i * kWave + lane);
+                    d2 v = {0.0, 0.0};
+                    if (e < seg_len) v.x = src[base + e];
+                    if (e + 1 < seg_len) v.y = src[base + e + 1];
+                    pre[i] = v;
+                }
+            }
+        };
+
+        auto front_step = [&](int it, d2(&pre)[kPPieces]) {
+            char *tile = (it & 1) ? tile1 : tile0;
+            __syncthreads();                                 /* barrier 0 */
+            if (it < nseg) {
+#pragma unroll
+                for (int i = 0; i < kPPieces; ++i)
+                    *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
+            }
+            __syncthreads();                                 /* barrier 1 */
+            if (it >= nseg) return;
+            fetch(it + 2, pre);
+
+            const bool seeded = seed_stream && it == 0;
+            const double tailv = seed_stream ? 0.0 : tail0;
+            const char *row = tile + lane * (PT * 8);
+            double v[N + 1];
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = 0.0;
+            v[N] = tailv;
+#pragma unroll 2
+            for (int q = 0; q < PT / 2; ++q) {
+                const d2 xv = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[(2 * q) * N + i], xv.x, v[i]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[(2 * q + 1) * N + i], xv.y, v[i]);
+            }
+            if (tailv != 0.0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[PT * N + i], tailv, v[i]);
+            }
+            if (seeded && lane == 0) {
+                /* row 0 of a fresh stream: RTIIRFilter_stable_init on sample 0, then the recurrence;
+                 * its end state does not depend on any carried state */
+#pragma unroll
+                for (int i = 0; i <= N; ++i) v[i] = 0.0;
+                const size_t left = n < (size_t)PT ? n : (size_t)PT;
+                (void)iir_seed_ref<N>(*reinterpret_cast<const double *>(row + (0 ^ rx)), v, b, a);
+                for (int k = 1; k < (int)left; ++k)
+                    (void)iir_step_fused<N, kUnitA0>(
+                        *reinterpret_cast<const double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8), v, b, a);
+            }
+
+            /* Kogge-Stone over the 64 rows, zero carry-in */
+            for (int lvl = 0; lvl < nlev; ++lvl) {
+                const int d = 1 << lvl;
+                const double *M = mats + lvl * N * N;
+                constexpr int kAhead = N < 3 ? N : 3;
+                double mc[kAhead][N];
+#pragma unroll
+                for (int c = 0; c < kAhead; ++c) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) mc[c][i] = M[c * N + i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double u[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) u[i] = __shfl_up(v[i], d, kWave);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double col[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) col[i] = mc[j % kAhead][i];
+                    if (j + kAhead < N) {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) mc[j % kAhead][i] = M[(j + kAhead) * N + i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (lane >= d) {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) v[i] = __builtin_fma(col[i], u[j], v[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            /* publish: row j+1 starts (with zero carry-in) from the state row j ends in */
+            if (lane < kPRows - 1) {
+                double *slot = pbuf + (lane + 1) * N;
+#pragma unroll
+                for (int i = 0; i < N; ++i) slot[i] = v[i];
+            }
+        };
+
+        fetch(0, pre0);
+        fetch(1, pre1);
+        for (int it = 0; it <= nseg; it += 2) {
+            front_step(it, pre0);
+            if (it + 1 <= nseg) front_step(it + 1, pre1);
+        }
+    } else {
+        /* =============================== BACK ================================ */
+        double carry[N + 1];
+        {
+            const double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+            for (int i = 0; i <= N; ++i) carry[i] = st[i];
+        }
+        double ylast = g.fval[gi];
+        /* this lane's propagator A^(32*lane), row-major, resident for the whole launch */
+        double tp[N * N];
+        {
+            const double *tt = g.pows + g.ttab_off[dsn] + (size_t)lane * N * N;
+#pragma unroll
+            for (int e = 0; e < N * N; ++e) tp[e] = tt[e];
+        }
+
+        for (int it = 0; it <= nseg; ++it) {
+            const int seg = it - 1;
+            char *tile = (seg & 1) ? tile1 : tile0;
+            __syncthreads();                                 /* barrier 0 */
+            double s[N + 1];
+            if (seg >= 0) {
+                const double *slot = pbuf + lane * N;
+#pragma unroll
+                for (int i = 0; i < N; ++i) s[i] = slot[i];
+            }
+            __syncthreads();                                 /* barrier 1 */
+            if (seg < 0) continue;
+
+            const size_t base = (size_t)seg * kPSeg;
+            const size_t left = n - base;
+            const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
+            const bool seeded = seed_stream && seg == 0;
+            const bool fast = seg_len == kPSeg && !seeded;
+
+            /* s_j = P_j + A^(32 j) carry  (row 0: P = 0, A^0 = I) */
+            if (!seeded) {
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) s[i] = __builtin_fma(tp[i * N + q], carry[q], s[i]);
+                }
+                s[N] = carry[N];
+            } else {
+                s[N] = 0.0;
+            }
+
+            char *row = tile + lane * (PT * 8);
+            double y = ylast;
+            if (fast) {
+#pragma unroll 4
+                for (int q = 0; q < PT / 2; ++q) {
+                    d2 xv = *reinterpret_cast<d2 *>(row + ((q << 4) ^ rx));
+                    xv.x = iir_step_fused<N, kUnitA0>(xv.x, s, b, a);
+                    xv.y = y = iir_step_fused<N, kUnitA0>(xv.y, s, b, a);
+                    *reinterpret_cast<d2 *>(row + ((q << 4) ^ rx)) = xv;
+                }
+            } else {
+                int cnt = seg_len - lane * PT;
+                cnt = cnt < 0 ? 0 : (cnt > PT ? PT : cnt);
+                int k = 0;
+                if (seeded && lane == 0) {
+                    double *p0 = reinterpret_cast<double *>(row + (0 ^ rx));
+                    y = iir_seed_ref<N>(*p0, s, b, a);
+                    *p0 = y;
+                    k = 1;
+                }
+                for (; k < cnt; ++k) {
+                    double *pk = reinterpret_cast<double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8);
+                    y = iir_step_fused<N, kUnitA0>(*pk, s, b, a);
+                    *pk = y;
+                }
+            }
+            const int jlast = (seg_len - 1) / PT;
+#pragma unroll
+            for (int i = 0; i <= N; ++i) carry[i] = __shfl(s[i], jlast, kWave);
+            ylast = __shfl(y, jlast, kWave);
+
+            /* store the segment, coalesced (this wave wrote the whole tile: in-order LDS) */
+            wave_sync();
+            if (seg_len == kPSeg && io.aligned16) {
+#pragma unroll 8
+                for (int i = 0; i < kPPieces; ++i)
+                    *reinterpret_cast<d2 *>(dst + base + 2 * (i * kWave + lane)) =
+                        *reinterpret_cast<const d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]);
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < kPPieces; ++i) {
+                    const int e = 2 * (i * kWave + lane);
+                    const d2 ov = *reinterpret_cast<const d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]);
+                    if (e < seg_len) dst[base + e] = ov.x;
+                    if (e + 1 < seg_len) dst[base + e + 1] = ov.y;
+                }
+            }
+        }
+
+        if (lane == 0) {
+            double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+            for (int i = 0; i <= N; ++i) st[i] = carry[i];
+            g.fval[gi] = ylast;
+            g.init[gi] = 0;
+        }
+    }
+}
+
+template <int N>
+static hipError_t launch_pipe_n(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    int levels = g.levels2_max > kPLevels ? kPLevels : g.levels2_max;
+    const size_t lds = 2 * kPTile + sizeof(double) * ((size_t)levels * N * N + (size_t)kPRows * N);
+    if (g.unit_a0)
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, levels);
+    else
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, levels);
+    return hipGetLastError();
+}
+
+hipError_t launch_iir_pipe(int order, const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    switch (order) {
+        case 1: return launch_pipe_n<1>(g, io, s);
+        case 2: return launch_pipe_n<2>(g, io, s);
+        case 3: return launch_pipe_n<3>(g, io, s);
+        case 4: return launch_pipe_n<4>(g, io, s);
+        case 5: return launch_pipe_n<5>(g, io, s);
+        case 6: return launch_pipe_n<6>(g, io, s);
+        case 7: return launch_pipe_n<7>(g, io, s);
+        case 8: return launch_pipe_n<8>(g, io, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dsp

@@ -127,6 +127,12 @@ EXPORT size_t dsp_pool_bytes_cached(int device);
  * written on device to dst + c*ld + k, c < nch, k < n. */
 EXPORT int dsp_synth_fill(double *dst, size_t ld, size_t nch, size_t n,
                           uint64_t seed, uint64_t chan0, uint64_t n0, void *hip_stream);
+/* Compute-free twin of the IIR scan kernels' memory access pattern: one workgroup per row walks
+ * its n doubles in `seg`-double pieces (two pieces of loads in flight), out[c*ld_out+k] =
+ * in[c*ld_in+k].  bench.py times it to report the streaming-copy ceiling of the device next to the
+ * roofline fraction.  threads in {64,128,256}; seg divides n; rows 16-byte aligned. */
+EXPORT int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
+                         size_t n, int threads, int seg, void *hip_stream);
 EXPORT int dsp_device_count(void);
 EXPORT int dsp_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device);
 EXPORT int dsp_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device);

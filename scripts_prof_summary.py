@@ -29,7 +29,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
         acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("== %s: per-launch mean of each counter ==" % sub)
     for k, cs in acc.items():
-        if "scan" not in k and "seq" not in k and "fir" not in k:
+        if not any(t in k for t in ("scan", "seq", "fir", "pipe")):
             continue
         print(k[:100])
         for c, vals in sorted(cs.items()):
