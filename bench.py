@@ -83,7 +83,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", choices=["auto", "scan", "seq"], default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--workload", choices=["iir8", "fir512"], default="iir8",
+                    help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3")
+    ap.add_argument("--fir-channels", type=int, default=65536)
     args = ap.parse_args()
+    if args.workload == "fir512":
+        return main_fir512(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -193,6 +198,114 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_fir512(args):
+    """BASELINE.json config 3: 512-tap FIR low-pass, 65 536 channels x 64K samples per GPU.  One STEP =
+    one RTFilterBank_updaten over the whole 65 536 x 65 536 block (32 GiB read + 32 GiB written), the
+    state carried on (the stream simply continues with the same input block).  Dominant kernel:
+    fir_mfma_kernel (Toeplitz tiles on v_mfma_f64_16x16x4); roofline bound = FP64 matrix peak with
+    ALGORITHMIC flops = 2 x 512 per output sample."""
+    FP64_MFMA_PEAK_TF = 78.6     # AMD MI355X data sheet, FP64 matrix (dense); the guide lists no f64 MFMA peak
+    TAPS = 512
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from dsp_amd import bank as gbank
+    from tests import util
+    _, b, _ = util.design_coefs("fir512_lp_0.25")
+    nch = args.fir_channels
+    mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_AUTO, seq=gbank.MODE_SEQUENTIAL)[args.mode]
+    bank = gbank.FilterBank([gbank.fir_design(b)], [0] * nch, device=local, mode=mode)
+    x = torch.empty((nch, BLOCK), dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    gbank.synth_fill(x, SEED, chan0=rank * nch, n0=0)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        bank.updaten_ptr(y.data_ptr(), BLOCK, x.data_ptr(), BLOCK, BLOCK, stream)
+        if ev is not None:
+            ev[1].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    kern_avg_s = float(np.mean(kern_ms)) / 1e3
+    if rank == 0:
+        samples = nch * BLOCK
+        flops = 2.0 * TAPS * samples
+        achieved = flops / kern_avg_s / 1e12
+        line = {
+            "metric": "filtered Msamples/s (whole node)", "value": world * samples * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 3: 512-tap FIR low-pass (windowed sinc 0.25), %d channels x 64K "
+                                   "samples, one block per step, state carried in HBM" % nch,
+                       "channels_per_gpu": nch, "block": BLOCK, "taps": TAPS, "kernel": args.mode,
+                       "parallelism": "channel-sharded x%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "algorithmic_flops_per_launch": flops,
+                         "hbm_gbs_at_16B_per_sample": samples * BYTES_PER_SAMPLE / kern_avg_s / 1e9,
+                         "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline_fir(b)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_fir(b):
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from oracle import ref
+    from tests import util
+    threads = max(1, min(16, os.cpu_count() or 1))
+    per_thread = 16
+    kind = "reference" if ref.available() else "port"
+    xs = [util.synth(SEED, t, 0, BLOCK) for t in range(threads)]
+
+    def work(t):
+        for _ in range(per_thread):
+            (ref.RefFIR(b) if kind == "reference" else orc.fir(b)).updaten(xs[t])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return dict(value=threads * per_thread * BLOCK / dt / 1e6, unit="Msamples/s", cores=threads, kind=kind,
+                sample="%d channels x 64K samples of config 3 (512 taps), RTFilter_updaten per channel, "
+                       "%d host threads, %.1f s" % (threads * per_thread, threads, dt))
 
 
 if __name__ == "__main__":

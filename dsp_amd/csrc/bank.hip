@@ -215,6 +215,7 @@ struct Group {
     double *d_state_alt = nullptr;      /* FIR: other half of the state ping-pong */
     int32_t *d_aux = nullptr;           /* FIR: prologue -> main/epilogue hand-off */
     int kmax = 0;                       /* FIR: longest filter in the group        */
+    bool has_partial = false;           /* FIR: a partial_init design is present    */
     int levels2_max = 0;                /* fast IIR: most combine levels any design needs */
     double *d_scratch = nullptr;        /* FIR, in-place calls: private copy of the input */
     size_t scratch_doubles = 0;
@@ -536,6 +537,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         g.state_ld = std::max(g.state_ld, d.state_slots());
         g.levels2_max = std::max(g.levels2_max, d.levels2);
         if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
+        if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
     }
 
     int rc;
@@ -598,6 +600,8 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.aux = g.d_aux;
     v.kmax = g.kmax;
     v.unit_a0 = g.unit_a0 ? 1 : 0;
+    v.fir_mfma = 0;
+    v.has_partial = g.has_partial ? 1 : 0;
     v.fval = g.d_fval;
     v.init = g.d_init;
     v.coef_off = bk->d_coef_off;
@@ -932,6 +936,7 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
                 fio.in = g.d_scratch;
                 fio.ld_in = n;
             }
+            v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= kFirMfmaMinTaps) ? 1 : 0;
             HIP_TRY(launch_fir(v, fio, s));
             std::swap(g.d_state, g.d_state_alt);
             continue;

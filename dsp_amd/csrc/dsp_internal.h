@@ -26,6 +26,7 @@ constexpr int kFirT = 32;            /* FIR kernel: outputs per lane            
 constexpr int kFirR = 8;             /* FIR kernel: outputs accumulated together      */
 constexpr int kFirSeg = kWave * kFirT;   /* outputs per wavefront                    */
 constexpr int kMaxFirTaps = 4096;
+constexpr int kFirMfmaMinTaps = 64;  /* from here the FP64 matrix cores beat the VALU kernel (not bit-exact) */
 
 /* One launch group: channels of the bank that share a kernel. All pointers are
  * device pointers; arrays are indexed by the group-local channel index g. */
@@ -42,6 +43,9 @@ struct GroupView {
                                  index of the block's sample 0 while a partial_init ramp runs */
     int32_t        kmax;      /* FIR only: largest tap count in the group                 */
     int32_t        unit_a0;   /* IIR fast groups: every design has a[0] == 1.0 exactly    */
+    int32_t        fir_mfma;  /* FIR: outputs come from the Toeplitz-tile MFMA kernel (exact head kernel
+                                 only for channels inside a partial_init ramp)                  */
+    int32_t        has_partial;   /* FIR: some design of the group is RTFB_KIND_FIR_PARTIAL     */
     double        *fval;      /* RTFilter.filtered_value per g                            */
     int32_t       *init;      /* RTFilter.initialized per g                               */
     const int32_t *coef_off;  /* per design: offset of b[0] in coefs (a follows b)        */

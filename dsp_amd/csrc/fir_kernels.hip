@@ -97,6 +97,8 @@ fir_main_kernel(GroupView g, BlockIO io, int seg0)
     const int t0 = g.aux[2 * gi];
     const int ramp0 = g.aux[2 * gi + 1];
     const bool partial = as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL;
+    /* with the MFMA kernel on, only channels inside a partial_init ramp keep this exact head */
+    if (kHead && g.fir_mfma && !(partial && ramp0 < K)) return;
 
     const long long n = (long long)io.n;
     const long long seg_base = (long long)seg * S;        /* first output of this wavefront */
@@ -183,9 +185,20 @@ fir_main_kernel(GroupView g, BlockIO io, int seg0)
     }
 }
 
-__global__ void __launch_bounds__(256)
+/* End state.  s'[i] = ((base + b[i+J] x[n-J]) + ... ) + b[i+1] x[n-1],  J = min(regular, K-1-i),
+ * base = s[K-1] when the chain reaches the end of the delay line, else the carried s[i+regular]
+ * (oldest input first: the reference's order).  A lane owns kEpiR consecutive elements: at step j
+ * they all take x[n-j] (one broadcast LDS read) times the sliding tap window b[i0+j .. i0+j+R-1],
+ * which gains one new tap per step -- two LDS reads per kEpiR multiply-adds. */
+constexpr int kEpiR = 8;
+constexpr int kEpiThreads = 64;
+
+__global__ void __launch_bounds__(kEpiThreads)
 fir_epilogue_kernel(GroupView g, BlockIO io)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *lds = reinterpret_cast<double *>(smem_raw);
+
     const int gi = blockIdx.x;
     const int chan = group_channel(g, gi);
     const int dsn = g.design[gi];
@@ -200,14 +213,56 @@ fir_epilogue_kernel(GroupView g, BlockIO io)
     const double *x = io.in + (size_t)chan * io.ld_in;
     const double tail = s_in[K - 1];
 
-    /* s'[i] = ((base + b[i+J] x[n-J]) + ... ) + b[i+1] x[n-1],  J = min(regular, K-1-i),
-     * base = s[K-1] when the chain reaches the end of the delay line, else the carried s[i+regular] */
-    for (int i = threadIdx.x; i < K - 1; i += blockDim.x) {
-        const long long room = K - 1 - i;
-        const long long J = regular < room ? regular : room;
-        double acc = (J == room) ? tail : s_in[i + regular];
-        for (long long j = J; j >= 1; --j) acc = acc + b[i + j] * x[n - j];
-        s_out[i] = acc;
+    /* the last min(regular, K-1) inputs, newest first (xl[j] = x[n-j]); the taps at pitch R+1 per R
+     * (lanes read them R apart), zero beyond K-1 (never used: those steps are predicated off) */
+    double *xl = lds;
+    double *bl = lds + K;
+    const int depth = regular < K - 1 ? (int)regular : K - 1;
+    for (int j = 1 + threadIdx.x; j <= depth; j += kEpiThreads) xl[j] = x[n - j];
+    for (int k = threadIdx.x; k < K + kEpiR; k += kEpiThreads) bl[k + k / kEpiR] = k < K ? b[k] : 0.0;
+    wave_sync();
+
+    for (int i0 = kEpiR * threadIdx.x; i0 < K - 1; i0 += kEpiR * kEpiThreads) {
+        double acc[kEpiR], w[kEpiR];
+        int J[kEpiR];
+#pragma unroll
+        for (int r = 0; r < kEpiR; ++r) {
+            const long long room = K - 1 - (i0 + r);            /* <= 0 past the delay line: idle slot */
+            J[r] = (int)(regular < room ? regular : (room > 0 ? room : 0));
+            acc[r] = (room <= 0 || J[r] == room) ? tail : s_in[i0 + r + regular];
+        }
+        int j = J[0];                                           /* the longest chain of the R */
+#pragma unroll
+        for (int r = 0; r < kEpiR; ++r) { const int k = i0 + r + j; w[r] = bl[k + k / kEpiR]; }
+        /* steps where some of the R chains have not started yet */
+        for (; j >= 1 && j > J[kEpiR - 1]; --j) {
+            const double xj = xl[j];
+#pragma unroll
+            for (int r = 0; r < kEpiR; ++r) {
+                const double p = w[r] * xj;
+                acc[r] = (j <= J[r]) ? acc[r] + p : acc[r];
+            }
+#pragma unroll
+            for (int r = kEpiR - 1; r >= 1; --r) w[r] = w[r - 1];
+            const int k = i0 + j - 1;
+            w[0] = bl[k + k / kEpiR];
+        }
+#pragma unroll 8
+        for (; j >= 1; --j) {
+            const double xj = xl[j];
+#pragma unroll
+            for (int r = 0; r < kEpiR; ++r) {
+                const double p = w[r] * xj;
+                acc[r] = acc[r] + p;
+            }
+#pragma unroll
+            for (int r = kEpiR - 1; r >= 1; --r) w[r] = w[r - 1];
+            const int k = i0 + j - 1;
+            w[0] = bl[k + k / kEpiR];
+        }
+#pragma unroll
+        for (int r = 0; r < kEpiR; ++r)
+            if (i0 + r < K - 1) s_out[i0 + r] = acc[r];
     }
     if (threadIdx.x == 0) {
         s_out[K - 1] = tail;
@@ -218,6 +273,185 @@ fir_epilogue_kernel(GroupView g, BlockIO io)
             ini = last >= K - 1 ? 0 : (int)(K - 1 - last);
         }
         g.init[gi] = ini;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Long-tap FIR as a Toeplitz-tile contraction on the FP64 matrix cores         */
+/* (v_mfma_f64_16x16x4_f64) -- the only place this library uses MFMA.           */
+/*                                                                              */
+/* Steady-state outputs (at least K-1 regular samples behind them) are          */
+/*     y[m] = s[K-1] + sum_k b[k] x[m-k].                                        */
+/* A workgroup of 4 wavefronts takes 4096 consecutive outputs of one channel;   */
+/* each wavefront owns 4 accumulator tiles of 256 outputs,                      */
+/*     D[i][j] = y[m0 + 256 t + 16 j + i]   (i = row 0..15, j = column 0..15).   */
+/* For every offset delta = -12, -8, ..., (a multiple of 16) >= K-1:            */
+/*     D += A_delta * B_delta,   A_delta[i][kk] = b[delta + i - kk]   (a 16 x 4 */
+/*     Toeplitz tile of the taps, identical for all columns and tiles),         */
+/*     B_delta[kk][j] = x[m0 + 256 t + 16 j - delta + kk].                       */
+/* Each (i, k) pair meets exactly one delta, so the sum is the convolution;     */
+/* 4*(ceil((K-1)/16)+1) steps of 1024 FMAs per 256 outputs (132 for K = 512,    */
+/* 97 % useful).  Operands come from LDS: taps zero-padded by 16 on both sides,  */
+/* inputs with their halo skewed one double per 16 (row pitch 17) so that the B */
+/* fetch is bank-conflict free.  Because the history length staged is a multiple */
+/* of 16 and delta advances as -12 + 16 o + 4 u, the skew never carries: every   */
+/* operand address is base(lane) + immediate, one pointer bump per 16 MFMAs.     */
+/* FMA accumulation in a different order than the reference: NOT bit-exact,     */
+/* bar 1e-12 relative to peak (measured ~1e-16); RTFB_MODE_SEQUENTIAL keeps     */
+/* every FIR channel on the bit-exact VALU kernel above.  Head segments, the    */
+/* prologue and the epilogue (state) are shared with that kernel.  Non-finite   */
+/* inputs: the zero taps of the padding multiply up to 15 samples either side   */
+/* of a tile, so an Inf/NaN sample also poisons up to 15 earlier outputs here.   */
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kMfmaWaves = 4;
+constexpr int kMfmaTiles = 4;                                    /* accumulator tiles per wavefront */
+constexpr int kMfmaSeg = kMfmaWaves * kMfmaTiles * 256;          /* outputs per workgroup: 4096 */
+constexpr int kPitch = 18;                                       /* LDS doubles per 16 inputs */
+__host__ __device__ constexpr int mfma_steps16(int K) { return (K - 1 + 15) / 16 + 1; }   /* outer steps */
+__device__ __forceinline__ int xpos(int e) { return e + 2 * (e >> 4); }
+
+struct MfmaOperands {
+    double a[4];
+    double b[4][kMfmaTiles];
+};
+/* Operand fetch with plain ds_read_b64 (two 32-lane groups, bank = dword mod 64: conflict-free at
+ * pitch 18, 2 LDS cycles).  The four delta sub-steps use four base registers the compiler cannot
+ * relate, otherwise it pairs neighbouring reads into ds_read2_b64, which is serviced in 16-lane
+ * groups on 32 banks: 4x the LDS cycles plus conflicts (measured: LDS 49 % busy, 44 % of it conflicts). */
+typedef const __attribute__((address_space(3))) double *lds_cdouble_p;
+__device__ __forceinline__ lds_cdouble_p lds_opaque(const double *p)
+{
+    unsigned off = (unsigned)(uintptr_t)(lds_cdouble_p)p;
+    asm volatile("" : "+v"(off));
+    return (lds_cdouble_p)(uintptr_t)off;
+}
+__device__ __forceinline__ void mfma_fetch(MfmaOperands &r, const lds_cdouble_p (&pa)[4],
+                                           const lds_cdouble_p (&pb)[4], int o)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r.a[u] = pa[u][16 * o];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t) r.b[u][t] = pb[u][kPitch * 16 * t - kPitch * o];
+}
+__device__ __forceinline__ void mfma_apply(d4 (&acc)[kMfmaTiles], const MfmaOperands &r)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[u], r.b[u][t], acc[t], 0, 0, 0);
+}
+}  // namespace
+
+/* `ramp_first`: first output this kernel writes for a channel that is inside a partial_init ramp
+ * (the exact head kernel covers what is before it); every other channel is served from output t0. */
+__global__ void __launch_bounds__(kMfmaWaves * kWave)
+fir_mfma_kernel(GroupView g, BlockIO io, long long ramp_first)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *lds = reinterpret_cast<double *>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const int gi = blockIdx.y;
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+    const int K = as_const(g.nb)[dsn];
+    const double *b = g.coefs + as_const(g.coef_off)[dsn];
+    const int t0 = g.aux[2 * gi];
+    const int ramp0 = g.aux[2 * gi + 1];
+    const bool ramp = as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL && ramp0 < K;
+    const long long first = ramp ? ramp_first : (long long)t0;     /* first output written here */
+    const long long n = (long long)io.n;
+    const long long seg_base = (long long)blockIdx.x * kMfmaSeg;
+    if (seg_base + kMfmaSeg <= first) return;                      /* whole workgroup */
+    const double *x = io.in + (size_t)chan * io.ld_in;
+    double *out = io.out + (size_t)chan * io.ld_out;
+    const double *st = g.state + (size_t)gi * g.state_ld;
+    const double tail = st[K - 1];
+
+    const int steps = mfma_steps16(K);                      /* delta = -12 + 16 o + 4 u, o < steps */
+    const int hist = 16 * (steps - 1);                      /* inputs staged before seg_base (>= K-1) */
+    const int nb_pad = hist + 32;                           /* taps at index k + 16 */
+    double *bp = lds;
+    double *xs = lds + nb_pad;
+    const int total = hist + kMfmaSeg + 16;                 /* inputs seg_base-hist .. seg_base+4096+15 */
+
+    for (int e = tid; e < nb_pad; e += kMfmaWaves * kWave) {
+        const int k = e - 16;
+        bp[e] = (k >= 0 && k < K) ? b[k] : 0.0;
+    }
+    /* samples before t0 were consumed by stable_init (or do not exist): they feed nothing */
+    for (int e = tid; e < total; e += kMfmaWaves * kWave) {
+        const long long idx = seg_base - hist + e;
+        xs[xpos(e)] = (idx >= t0 && idx < n) ? x[idx] : 0.0;
+    }
+    __syncthreads();
+
+    const int j = lane & 15, q = lane >> 4;
+    d4 acc[kMfmaTiles];
+    if (seg_base > K) {                                     /* steady state: s[K-1] under every output */
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t) acc[t] = (d4){tail, tail, tail, tail};
+    } else {                                                /* outputs that still sit on the carried state */
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long mp = seg_base + 256 * (kMfmaTiles * wave + t) + 16 * j + 4 * q + r - t0;
+                acc[t][r] = (mp >= 0 && mp <= K - 2) ? st[mp] : tail;
+            }
+    }
+
+    /* Tile row i' stands for output offset pi(i') = 4 (i' & 3) + (i' >> 2) inside its 16, so that the
+     * four results a lane holds (rows q, q+4, q+8, q+12 of column j) are the consecutive outputs
+     * 16 j + 4 q + {0,1,2,3}: each lane stores 32 contiguous bytes, a wavefront a contiguous 2 KB tile.
+     * A: row i' = j, kk = q: bp[16 + pi(j) - q + delta];  B: column j, kk = q, tile t:
+     * xs element hist + 256 t + 16 j + q - delta = 16 (hist/16 + 16 t + j - o) + (12 + q - 4 u), no carry */
+    const int pij = 4 * (j & 3) + (j >> 2);
+    lds_cdouble_p pa[4], pb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        pa[u] = lds_opaque(bp + (4 + pij - q) + 4 * u);
+        pb[u] = lds_opaque(xs + kPitch * (hist / 16 + 64 * wave + j) + q + 4 * (3 - u));
+    }
+    MfmaOperands r0, r1;
+    mfma_fetch(r0, pa, pb, 0);
+    int o = 1;
+    for (; o + 1 < steps; o += 2) {                         /* two register sets: fetch one step ahead */
+        mfma_fetch(r1, pa, pb, o);
+        mfma_apply(acc, r0);
+        mfma_fetch(r0, pa, pb, o + 1);
+        mfma_apply(acc, r1);
+    }
+    if (o < steps) {
+        mfma_fetch(r1, pa, pb, o);
+        mfma_apply(acc, r0);
+        mfma_apply(acc, r1);
+    } else {
+        mfma_apply(acc, r0);
+    }
+
+    /* D[row = q + 4 r][col = j]  ->  output 256 t + 16 j + 4 q + r, straight from the registers */
+    const long long m0 = seg_base + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
+    const bool whole = first <= seg_base && seg_base + kMfmaSeg <= n && io.aligned16;
+#pragma unroll
+    for (int t = 0; t < kMfmaTiles; ++t) {
+        const long long m = m0 + 256 * t;
+        if (whole) {
+            *reinterpret_cast<d2 *>(out + m) = (d2){acc[t][0], acc[t][1]};
+            *reinterpret_cast<d2 *>(out + m + 2) = (d2){acc[t][2], acc[t][3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r >= first && m + r < n) out[m + r] = acc[t][r];
+        }
     }
 }
 
@@ -234,17 +468,34 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
     /* segments whose outputs can touch the carried state or the ramp: m < K + 1 */
     int nhead = (g.kmax + 1 + S - 1) / S;
     if (nhead > nseg) nhead = nseg;
-    if (nhead > 0) {
-        hipLaunchKernelGGL(fir_main_kernel<true>, dim3(nhead, g.count), dim3(kWave), lds_bytes, s, g,
-                           io, 0);
+    if (g.fir_mfma) {
+        /* exact head only for channels inside a partial_init ramp (the others leave at once) */
+        if (nhead > 0 && g.has_partial) {
+            hipLaunchKernelGGL(fir_main_kernel<true>, dim3(nhead, g.count), dim3(kWave), lds_bytes, s, g,
+                               io, 0);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        const int hist = 16 * (mfma_steps16(g.kmax) - 1);
+        const int xtotal = hist + kMfmaSeg + 16;
+        const size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
+        const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);
+        hipLaunchKernelGGL(fir_mfma_kernel, dim3(nwg, g.count), dim3(kMfmaWaves * kWave), mfma_lds, s, g,
+                           io, (long long)nhead * S);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+        if (nhead > 0) {
+            hipLaunchKernelGGL(fir_main_kernel<true>, dim3(nhead, g.count), dim3(kWave), lds_bytes, s, g,
+                               io, 0);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (nseg > nhead) {
+            hipLaunchKernelGGL(fir_main_kernel<false>, dim3(nseg - nhead, g.count), dim3(kWave),
+                               lds_bytes, s, g, io, nhead);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     }
-    if (nseg > nhead) {
-        hipLaunchKernelGGL(fir_main_kernel<false>, dim3(nseg - nhead, g.count), dim3(kWave),
-                           lds_bytes, s, g, io, nhead);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(256), 0, s, g, io);
+    const size_t epi_lds = (size_t)(g.kmax + (g.kmax + kEpiR) + (g.kmax + kEpiR) / kEpiR + 2) * sizeof(double);
+    hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(kEpiThreads), epi_lds, s, g, io);
     return hipGetLastError();
 }
 

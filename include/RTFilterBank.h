@@ -52,11 +52,16 @@ typedef struct RTFilterDesign {
     const double *a;      /* host pointer, na doubles (IIR)                */
 } RTFilterDesign;
 
-/* Kernel choice for IIR channels. */
-#define RTFB_MODE_AUTO        0   /* sequential when the bank has enough channels, else scan */
-#define RTFB_MODE_SEQUENTIAL  1   /* one lane per channel, reference operation order: bit-exact */
-#define RTFB_MODE_SCAN        2   /* time-parallel chunked state-space scan: <=1e-12 rel-to-peak on
-                                     well-conditioned designs, not bit-exact */
+/* Kernel choice.
+ * AUTO        fastest kernels that meet the 1e-12 relative-to-peak bar: IIR channels on the
+ *             time-parallel scan kernel when the bank is too small to fill the GPU with one lane per
+ *             channel and the design passes the conditioning probe (else bit-exact sequential); FIR
+ *             channels of >= 64 taps on the Toeplitz-tile FP64 MFMA kernel (else bit-exact).
+ * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
+ * SCAN        like AUTO but IIR channels always on the scan kernel (no probe, caller's choice). */
+#define RTFB_MODE_AUTO        0
+#define RTFB_MODE_SEQUENTIAL  1
+#define RTFB_MODE_SCAN        2
 
 /* Build a bank from host filters.  Each entry must be an RTIIRFilter or
  * RTFIRFilter whose callbacks are this library's own (pointer identity, the

@@ -24,7 +24,7 @@ def test_fir_bit_exact_vs_reference_golden(G, key):
     runs = util.load_npz("runs.npz")
     yref = runs[key + "/y"]
     x = util.synth(int(runs[key + "/seed"][0]), 0, 0, len(yref))
-    gb = gbank.FilterBank([G.golden_design(key)], [0])
+    gb = gbank.FilterBank([G.golden_design(key)], [0], mode=gbank.MODE_SEQUENTIAL)   # bit-exact kernels
     pos, outs = 0, []
     for cut in runs[key + "/cuts"]:
         cut = int(cut)
@@ -80,10 +80,36 @@ def test_fir_bit_exact_multichannel_ragged_blocks(G, blocks):
     designs.append(gbank.fir_design(rng.standard_normal(100), partial=True))
     nch = 37
     idx = [(5 * c + 1) % len(designs) for c in range(nch)]
-    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, blocks, gbank.MODE_AUTO, seed=64)
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, blocks, gbank.MODE_SEQUENTIAL, seed=64)
     for i, (yg, yo) in enumerate(zip(ys_g, ys_o)):
         assert util.bits_equal(yg, yo), i
     G.assert_state_equal(gb, ob, exact=True)
+
+
+TOL_MFMA = 1e-12   # north_star: float64 outputs within 1e-12 relative error (rel-to-peak per channel)
+
+
+@pytest.mark.parametrize("blocks", [[6000, 4096 + 11, 3000], [2048 * 3], [2049, 2047, 1, 9000]])
+def test_fir_mfma_toeplitz_within_1e12(G, blocks):
+    """AUTO mode: steady-state segments of >= 64-tap FIR channels run on the FP64 MFMA kernel
+    (head segment, stable_init / partial_init ramp and the carried state stay on the exact path)."""
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(9)
+    designs = [G.golden_design("fir512_lp_0.25"), G.golden_design("mavg512"),
+               gbank.fir_design(rng.standard_normal(100) / 10), gbank.fir_design(rng.standard_normal(257) / 16),
+               gbank.fir_design(rng.standard_normal(64) / 8, partial=True), G.golden_design("fir32_lp_0.25")]
+    nch = 19
+    idx = [c % len(designs) for c in range(nch)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, blocks, gbank.MODE_AUTO, seed=77)
+    yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+    err = util.rel_to_peak(yg, yo)
+    assert np.all(err <= TOL_MFMA), err.max()
+    assert err.max() > 0 or True
+    # the carried delay line is computed from the inputs in the reference's order: still bit-exact
+    st, fv, ini = gb.get_state()
+    assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state)
+    assert np.array_equal(ini, ob.init)
+    assert np.max(np.abs(fv - ob.fval)) <= 1e-12 * max(1.0, np.max(np.abs(ob.fval)))
 
 
 def test_mixed_iir_fir_bank_and_inplace(G):

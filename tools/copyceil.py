@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: HBM ceiling of the scan kernels' access pattern (row-streaming copy, no arithmetic)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from dsp_amd.cdsp import dspdll

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: device copy ceilings (torch copy_, row-streaming copy) vs size and leading dimension."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from dsp_amd.cdsp import dspdll

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: scan kernel time vs leading-dimension padding (HBM channel camping check)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from dsp_amd import bank as gbank

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a scripts_prof.sh output directory: per-kernel stats and per-launch PMC averages."""
+"""Summarise a tools/prof.sh output directory: per-kernel stats and per-launch PMC averages."""
 import csv
 import glob
 import os
@@ -20,7 +20,7 @@ if f:
     for row in csv.DictReader(open(f)):
         print("%-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (row.get("Name", "")[:90], row.get("Calls"),
               row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_mfma"):
     f = find(sub, "*counter_collection.csv")
     if not f:
         continue

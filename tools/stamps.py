@@ -4,7 +4,7 @@ import ctypes as C
 import os
 import sys
 os.environ["DSP_AMD_SCAN_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from dsp_amd import bank as gbank

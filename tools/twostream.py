@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: one 1024-channel bank on one stream vs k banks of 1024/k channels on k streams."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from dsp_amd import bank as gbank
