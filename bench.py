@@ -291,7 +291,7 @@ def cpu_baseline_fir(b):
     from oracle import ref
     from tests import util
     threads = max(1, min(16, os.cpu_count() or 1))
-    per_thread = 16
+    per_thread = 960          # ~15 s of host work at ~67 Msamples/s
     kind = "reference" if ref.available() else "port"
     xs = [util.synth(SEED, t, 0, BLOCK) for t in range(threads)]
 

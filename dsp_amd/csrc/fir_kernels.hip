@@ -328,30 +328,29 @@ __device__ __forceinline__ lds_cdouble_p lds_opaque(const double *p)
     asm volatile("" : "+v"(off));
     return (lds_cdouble_p)(uintptr_t)off;
 }
+/* Sub-step u of outer step o: its tap column and the four input columns. */
 __device__ __forceinline__ void mfma_fetch(MfmaOperands &r, const lds_cdouble_p (&pa)[4],
-                                           const lds_cdouble_p (&pb)[4], int o)
+                                           const lds_cdouble_p (&pb)[4], int u, int o)
 {
+    r.a[u] = pa[u][16 * o];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r.a[u] = pa[u][16 * o];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < kMfmaTiles; ++t) r.b[u][t] = pb[u][kPitch * 16 * t - kPitch * o];
+    for (int t = 0; t < kMfmaTiles; ++t) r.b[u][t] = pb[u][kPitch * 16 * t - kPitch * o];
 }
-__device__ __forceinline__ void mfma_apply(d4 (&acc)[kMfmaTiles], const MfmaOperands &r)
+__device__ __forceinline__ void mfma_apply(d4 (&acc)[kMfmaTiles], const MfmaOperands &r, int u)
 {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < kMfmaTiles; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[u], r.b[u][t], acc[t], 0, 0, 0);
+    for (int t = 0; t < kMfmaTiles; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[u], r.b[u][t], acc[t], 0, 0, 0);
 }
 }  // namespace
 
-/* `ramp_first`: first output this kernel writes for a channel that is inside a partial_init ramp
+/* Edge items: the segments before `steady_lo` (outputs that still draw on the carried state, the
+ * first regular sample, a ramp head handed over by the exact kernel) and from `steady_hi` on (the
+ * ragged end of the block).  One workgroup per item, everything guarded.
+ * `ramp_first`: first output this kernel writes for a channel that is inside a partial_init ramp
  * (the exact head kernel covers what is before it); every other channel is served from output t0. */
 __global__ void __launch_bounds__(kMfmaWaves * kWave)
-fir_mfma_kernel(GroupView g, BlockIO io, long long ramp_first)
+fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_lo, int steady_hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);
@@ -369,7 +368,8 @@ fir_mfma_kernel(GroupView g, BlockIO io, long long ramp_first)
     const bool ramp = as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL && ramp0 < K;
     const long long first = ramp ? ramp_first : (long long)t0;     /* first output written here */
     const long long n = (long long)io.n;
-    const long long seg_base = (long long)blockIdx.x * kMfmaSeg;
+    const int seg = (int)blockIdx.x < steady_lo ? (int)blockIdx.x : (int)blockIdx.x - steady_lo + steady_hi;
+    const long long seg_base = (long long)seg * kMfmaSeg;
     if (seg_base + kMfmaSeg <= first) return;                      /* whole workgroup */
     const double *x = io.in + (size_t)chan * io.ld_in;
     double *out = io.out + (size_t)chan * io.ld_out;
@@ -421,22 +421,18 @@ fir_mfma_kernel(GroupView g, BlockIO io, long long ramp_first)
         pa[u] = lds_opaque(bp + (4 + pij - q) + 4 * u);
         pb[u] = lds_opaque(xs + kPitch * (hist / 16 + 64 * wave + j) + q + 4 * (3 - u));
     }
-    MfmaOperands r0, r1;
-    mfma_fetch(r0, pa, pb, 0);
-    int o = 1;
-    for (; o + 1 < steps; o += 2) {                         /* two register sets: fetch one step ahead */
-        mfma_fetch(r1, pa, pb, o);
-        mfma_apply(acc, r0);
-        mfma_fetch(r0, pa, pb, o + 1);
-        mfma_apply(acc, r1);
+    MfmaOperands r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mfma_fetch(r, pa, pb, u, 0);
+    for (int o = 1; o < steps; ++o) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mfma_apply(acc, r, u);
+            mfma_fetch(r, pa, pb, u, o);
+        }
     }
-    if (o < steps) {
-        mfma_fetch(r1, pa, pb, o);
-        mfma_apply(acc, r0);
-        mfma_apply(acc, r1);
-    } else {
-        mfma_apply(acc, r0);
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mfma_apply(acc, r, u);
 
     /* D[row = q + 4 r][col = j]  ->  output 256 t + 16 j + 4 q + r, straight from the registers */
     const long long m0 = seg_base + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
@@ -453,6 +449,181 @@ fir_mfma_kernel(GroupView g, BlockIO io, long long ramp_first)
                 if (m + r >= first && m + r < n) out[m + r] = acc[t][r];
         }
     }
+}
+
+/* One steady item: kMfmaSeg outputs of one channel with the whole window inside the block. */
+struct MfmaItem {
+    const double *x0;       /* input of the first staged element: x + seg_base - hist */
+    int emax;               /* last staged element that exists (the 16 look-ahead samples of the block's
+                               last segment do not: they repeat x[n-1] and only ever meet zero taps) */
+    double *out;            /* out + seg_base */
+    double tail;            /* s[K-1] */
+    const double *b;
+    int K, dsn, hist, steps;
+};
+
+constexpr int kMfmaPre = 19;    /* input doubles per thread fetched one item ahead: covers K <= 753 */
+
+__device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg)
+{
+    MfmaItem it;
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    it.dsn = as_const(g.design)[gi];
+    it.K = as_const(g.nb)[it.dsn];
+    it.b = g.coefs + as_const(g.coef_off)[it.dsn];
+    it.steps = mfma_steps16(it.K);                  /* delta = -12 + 16 o + 4 u, o < steps */
+    it.hist = 16 * (it.steps - 1);                  /* inputs staged before seg_base (>= K-1) */
+    const long long seg_base = (long long)seg * kMfmaSeg;
+    it.x0 = io.in + (size_t)chan * io.ld_in + (seg_base - it.hist);
+    const long long last = (long long)io.n - 1 - (seg_base - it.hist);
+    it.emax = last < it.hist + kMfmaSeg + 15 ? (int)last : it.hist + kMfmaSeg + 15;
+    it.out = io.out + (size_t)chan * io.ld_out + seg_base;
+    it.tail = as_const(g.state + (size_t)gi * g.state_ld)[it.K - 1];   /* written by an earlier kernel */
+    return it;
+}
+
+/* D[row = q + 4 r][col = j]  ->  output 256 t + 16 j + 4 q + r, straight from the registers */
+template <bool kAligned16>
+__device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *o0)
+{
+#pragma unroll
+    for (int t = 0; t < kMfmaTiles; ++t) {
+        if (kAligned16) {
+            *reinterpret_cast<d2 *>(o0 + 256 * t) = (d2){acc[t][0], acc[t][1]};
+            *reinterpret_cast<d2 *>(o0 + 256 * t + 2) = (d2){acc[t][2], acc[t][3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[256 * t + r] = acc[t][r];
+        }
+    }
+}
+
+/* Steady items (segments [steady_lo, steady_hi) of every channel: at least K regular samples behind
+ * the first output, the 16 look-ahead samples inside the block), persistent: the grid is sized to
+ * what the GPU holds at once and every workgroup walks a contiguous range of items (consecutive
+ * segments of a channel, then the next channel).  The inputs of the next item are fetched into
+ * registers before the contraction of the current one starts, so the global latency sits under
+ * ~34k cycles of MFMA work instead of in front of it.  No guards anywhere: all loads of a thread
+ * are in flight together and nothing makes the compiler drain vmcnt inside the item loop. */
+template <bool kAligned16>
+__global__ void __launch_bounds__(kMfmaWaves * kWave, 3)      /* 3 waves per SIMD: <= 168 VGPRs */
+fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *lds = reinterpret_cast<double *>(smem_raw);
+    constexpr int kThreads = kMfmaWaves * kWave;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int nseg = steady_hi - steady_lo;
+    const long long items = (long long)nseg * g.count;
+    long long idx = items * blockIdx.x / gridDim.x;
+    const long long idx_end = items * (blockIdx.x + 1) / gridDim.x;
+    if (idx >= idx_end) return;
+    int gi = (int)(idx / nseg);
+    int seg = (int)(idx - (long long)gi * nseg);
+
+    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg);
+    double xr[kMfmaPre];
+#pragma unroll
+    for (int k = 0; k < kMfmaPre; ++k) xr[k] = cur.x0[min(tid + kThreads * k, cur.emax)];
+    int staged_dsn = -1;
+    d4 acc[kMfmaTiles];
+    double *pending = nullptr;                                  /* where the previous item's results go */
+
+    for (; idx < idx_end; ++idx) {
+        double *bp = lds;                                       /* taps at index k + 16 */
+        const int nb_pad = cur.hist + 32;
+        double *xs = lds + nb_pad;
+        const int total = cur.hist + kMfmaSeg + 16;             /* inputs seg_base-hist .. seg_base+4096+15 */
+
+        lds_barrier();                                        /* the previous item's operand reads are over */
+        /* (first, so that the wait is for the prefetch only: the previous item's stores are younger) */
+#pragma unroll
+        for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
+        for (int e = tid + kThreads * kMfmaPre; e < total; e += kThreads)       /* very long filters */
+            xs[xpos(e)] = cur.x0[min(e, cur.emax)];
+        if (cur.dsn != staged_dsn) {
+            for (int e = tid; e < nb_pad; e += kThreads) {
+                const int k = e - 16;
+                bp[e] = (k >= 0 && k < cur.K) ? cur.b[k] : 0.0;
+            }
+            staged_dsn = cur.dsn;
+        }
+        /* The previous item's results leave only now: issued before the prefetch they would sit
+         * between it and the wait above, and the compiler, joining the loop entry (no stores) with
+         * the back edge, would wait for them too. */
+        if (pending) mfma_store<kAligned16>(acc, pending);
+        lds_barrier();
+
+        /* next item: its inputs travel while this one is contracted */
+        MfmaItem nxt = cur;
+        if (idx + 1 < idx_end) {
+            if (++seg == nseg) {                                /* next channel: a chain of scalar loads */
+                seg = 0;
+                ++gi;
+                nxt = mfma_item(g, io, gi, steady_lo);
+            } else {                                            /* next segment of the same channel */
+                nxt.x0 += kMfmaSeg;
+                nxt.out += kMfmaSeg;
+                const long long last = (long long)io.n - 1 - ((long long)(steady_lo + seg) * kMfmaSeg - cur.hist);
+                nxt.emax = last < cur.hist + kMfmaSeg + 15 ? (int)last : cur.hist + kMfmaSeg + 15;
+            }
+#pragma unroll
+            for (int k = 0; k < kMfmaPre; ++k) xr[k] = nxt.x0[min(tid + kThreads * k, nxt.emax)];
+        }
+
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t) acc[t] = (d4){cur.tail, cur.tail, cur.tail, cur.tail};
+
+        /* Tile row i' stands for output offset pi(i') = 4 (i' & 3) + (i' >> 2) inside its 16, so that
+         * the four results a lane holds (rows q, q+4, q+8, q+12 of column j) are the consecutive
+         * outputs 16 j + 4 q + {0,1,2,3}: each lane stores 32 contiguous bytes, a wavefront a
+         * contiguous 2 KB tile.  A: row i' = j, kk = q: bp[16 + pi(j) - q + delta];  B: column j,
+         * kk = q, tile t: xs element hist + 256 t + 16 j + q - delta
+         *                 = 16 (hist/16 + 16 t + j - o) + (12 + q - 4 u), no carry */
+        const int pij = 4 * (j & 3) + (j >> 2);
+        lds_cdouble_p pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pa[u] = lds_opaque(bp + (4 + pij - q) + 4 * u);
+            pb[u] = lds_opaque(xs + kPitch * (cur.hist / 16 + 64 * wave + j) + q + 4 * (3 - u));
+        }
+        /* one register set, software-pipelined: as soon as the four MFMAs of sub-step u have
+         * issued (operands are read at issue), its registers take the operands of the next outer
+         * step, which then have 12 MFMAs (768 cycles) to arrive */
+        MfmaOperands r;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mfma_fetch(r, pa, pb, u, 0);
+        for (int o = 1; o < cur.steps; ++o) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mfma_apply(acc, r, u);
+                mfma_fetch(r, pa, pb, u, o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mfma_apply(acc, r, u);
+
+        pending = cur.out + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
+        cur = nxt;
+    }
+    mfma_store<kAligned16>(acc, pending);
+}
+
+/* workgroups of fir_mfma_kernel the device holds at once for a given LDS size */
+static int mfma_resident_groups(size_t lds_bytes)
+{
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fir_mfma_kernel<true>, kMfmaWaves * kWave, lds_bytes) !=
+            hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return per_cu * cus;
 }
 
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
@@ -476,11 +647,33 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         const int hist = 16 * (mfma_steps16(g.kmax) - 1);
-        const int xtotal = hist + kMfmaSeg + 16;
+        int xtotal = hist + kMfmaSeg + 16;
+        if (xtotal < kMfmaPre * kMfmaWaves * kWave) xtotal = kMfmaPre * kMfmaWaves * kWave;
         const size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
-        const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);
-        hipLaunchKernelGGL(fir_mfma_kernel, dim3(nwg, g.count), dim3(kMfmaWaves * kWave), mfma_lds, s, g,
-                           io, (long long)nhead * S);
+        const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);       /* segments per channel */
+        /* steady segments: first output has more than kmax samples behind it (and lies past any
+         * ramp head: nhead*S <= steady_lo*kMfmaSeg), the whole segment is inside the block */
+        int steady_lo = g.kmax / kMfmaSeg + 1;
+        int steady_hi = (int)(io.n / kMfmaSeg);
+        if (steady_lo > nwg) steady_lo = nwg;
+        if (steady_hi < steady_lo) steady_hi = steady_lo;
+        const int nedge = steady_lo + (nwg - steady_hi);
+        if (nedge > 0) {
+            hipLaunchKernelGGL(fir_mfma_edge_kernel, dim3(nedge, g.count), dim3(kMfmaWaves * kWave), mfma_lds,
+                               s, g, io, (long long)nhead * S, steady_lo, steady_hi);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (steady_hi > steady_lo) {
+            const long long items = (long long)(steady_hi - steady_lo) * g.count;
+            long long grid = mfma_resident_groups(mfma_lds);
+            if (grid > items) grid = items;
+            if (io.aligned16)
+                hipLaunchKernelGGL(fir_mfma_kernel<true>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
+                                   mfma_lds, s, g, io, steady_lo, steady_hi);
+            else
+                hipLaunchKernelGGL(fir_mfma_kernel<false>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
+                                   mfma_lds, s, g, io, steady_lo, steady_hi);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
         if (nhead > 0) {

@@ -31,6 +31,16 @@ __device__ __forceinline__ cint_p as_const(const int32_t *p)
  * output stores that these kernels keep in flight across phases. */
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over
+ * every address space, which on gfx950 drains vmcnt: global loads prefetched across the barrier
+ * and stores still in flight would all be waited for. */
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int group_channel(const GroupView &g, int idx)
 {
     return g.chan ? g.chan[idx] : g.chan0 + idx;
