@@ -29,6 +29,8 @@ CHANNELS = 1024
 STREAM = 1 << 20
 BLOCK = 1 << 16
 NBLOCKS = STREAM // BLOCK
+PITCH = STREAM + 128             # row pitch in HBM (doubles): 1 KiB past a power of two, so that the 1024
+                                 # rows do not all start on the same HBM channel
 SEED = 0x5EED0002
 DESIGN = "bw4_bp_0.3_0.6"
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -106,8 +108,9 @@ def main():
     mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_SCAN, seq=gbank.MODE_SEQUENTIAL)[args.mode]
     bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
 
-    x = torch.empty((CHANNELS, STREAM), dtype=torch.float64, device=dev)
-    y = torch.empty_like(x)
+    xbuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
+    ybuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
+    x, y = xbuf[:, :STREAM], ybuf[:, :STREAM]
     gbank.synth_fill(x, SEED, chan0=rank * CHANNELS, n0=0)
     torch.cuda.synchronize()
 
@@ -120,7 +123,7 @@ def main():
             bank.reset(stream)
         if ev is not None:
             ev[0].record(stream)
-        bank.updaten_ptr(y.data_ptr() + j * BLOCK * 8, STREAM, x.data_ptr() + j * BLOCK * 8, STREAM,
+        bank.updaten_ptr(y.data_ptr() + j * BLOCK * 8, PITCH, x.data_ptr() + j * BLOCK * 8, PITCH,
                          BLOCK, stream)
         if ev is not None:
             ev[1].record(stream)
@@ -161,8 +164,8 @@ def main():
             j = k % NBLOCKS
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            rc = dspdll.dsp_copy_rows(C.c_void_p(y.data_ptr() + j * BLOCK * 8), STREAM,
-                                      C.c_void_p(x.data_ptr() + j * BLOCK * 8), STREAM, CHANNELS, BLOCK,
+            rc = dspdll.dsp_copy_rows(C.c_void_p(y.data_ptr() + j * BLOCK * 8), PITCH,
+                                      C.c_void_p(x.data_ptr() + j * BLOCK * 8), PITCH, CHANNELS, BLOCK,
                                       256, 8192, C.c_void_p(stream.cuda_stream))
             e1.record(stream)
             torch.cuda.synchronize()
@@ -184,7 +187,7 @@ def main():
                                    "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
-                       "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
+                       "row_pitch_doubles": PITCH, "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,

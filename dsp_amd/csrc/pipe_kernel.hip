@@ -127,13 +127,13 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
 
         auto front_step = [&](int it, d2(&pre)[kPPieces]) {
             char *tile = (it & 1) ? tile1 : tile0;
-            __syncthreads();                                 /* barrier 0 */
+            lds_barrier();                                    /* barrier 0 */
             if (it < nseg) {
 #pragma unroll
                 for (int i = 0; i < kPPieces; ++i)
                     *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
             }
-            __syncthreads();                                 /* barrier 1 */
+            lds_barrier();                                    /* barrier 1 */
             if (it >= nseg) return;
             fetch(it + 2, pre);
 
@@ -234,14 +234,14 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
         for (int it = 0; it <= nseg; ++it) {
             const int seg = it - 1;
             char *tile = (seg & 1) ? tile1 : tile0;
-            __syncthreads();                                 /* barrier 0 */
+            lds_barrier();                                    /* barrier 0 */
             double s[N + 1];
             if (seg >= 0) {
                 const double *slot = pbuf + lane * N;
 #pragma unroll
                 for (int i = 0; i < N; ++i) s[i] = slot[i];
             }
-            __syncthreads();                                 /* barrier 1 */
+            lds_barrier();                                    /* barrier 1 */
             if (seg < 0) continue;
 
             const size_t base = (size_t)seg * kPSeg;

@@ -155,7 +155,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
         for (int i = 0; i < kPiecesPerThread; ++i)
             *reinterpret_cast<d2 *>(tile + i * (8 * T2 * 8) + ((i & 1) ? st_odd : st_even)) = pre[i];
         stamp(6);
-        __syncthreads();
+        lds_barrier();   
         stamp(0);
         if (base + kSeg2 < n) fetch(base + kSeg2);
         stamp(1);
@@ -225,7 +225,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
 #pragma unroll
                 for (int i = 0; i < N; ++i) slot[i] = v[i];
             }
-            __syncthreads();
+            lds_barrier();   
             double u[N];
             if (d < 64) {
 #pragma unroll
@@ -267,7 +267,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
 #pragma unroll
             for (int i = 0; i < N; ++i) sbuf[i] = v[i];
         }
-        __syncthreads();
+        lds_barrier();   
         double s[N + 1];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -318,7 +318,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
             cbuf[N + 1] = y;
         }
         need_seed = false;
-        __syncthreads();
+        lds_barrier();   
 #pragma unroll
         for (int i = 0; i <= N; ++i) carry[i] = cbuf[i];
         ylast = cbuf[N + 1];
@@ -340,7 +340,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
             }
         }
         stamp(5);
-        __syncthreads();                                    /* tile is rewritten by the next park */
+        lds_barrier();                                       /* tile is rewritten by the next park */
         stamp(7);
     }
 
