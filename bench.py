@@ -66,11 +66,11 @@ def cpu_baseline(b, a):
                        "%d host threads, %.1f s" % (threads * per_thread, DESIGN, threads, dt))
 
 
-def measured_traffic():
+def measured_traffic(name="r1_traffic.json"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes).  None if
     the profile file is absent; bench.py itself does not run the profiler."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as fh:
             return json.load(fh)["hbm_bytes_per_launch"]
@@ -275,7 +275,8 @@ def main_fir512(args):
                        "channels_per_gpu": nch, "block": BLOCK, "taps": TAPS, "kernel": args.mode,
                        "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TF,
+                         "traffic": measured_traffic("r1_fir512_traffic.json") if nch == 65536 else None,
                          "algorithmic_flops_per_launch": flops,
                          "hbm_gbs_at_16B_per_sample": samples * BYTES_PER_SAMPLE / kern_avg_s / 1e9,
                          "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
