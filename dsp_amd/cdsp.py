@@ -163,6 +163,22 @@ _proto("dsp_memcpy_h2d", c_int, [c_void_p, c_void_p, c_size_t, c_int])
 _proto("dsp_memcpy_d2h", c_int, [c_void_p, c_void_p, c_size_t, c_int])
 _proto("dsp_stream_synchronize", c_int, [c_void_p, c_int])
 
+# ---- include/RTFilterStream.h -------------------------------------------------------------------
+_proto("RTFilterStream_from_design", c_int, [POINTER(c_void_p), POINTER(RTFilterDesign_), c_int])
+_proto("RTFilterStream_from_filter", c_int, [POINTER(c_void_p), c_void_p, c_int])
+_proto("RTFilterStream_destroy", None, [c_void_p])
+_proto("RTFilterStream_updaten", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p])
+_proto("RTFilterStream_reset", c_int, [c_void_p, c_void_p])
+_proto("RTFilterStream_sync_to_host", c_int, [c_void_p, c_void_p])
+_proto("RTFilterStream_decay_length", c_size_t, [c_void_p])
+_proto("RTFilterStream_last_split", c_size_t, [c_void_p])
+_proto("RTFilterStream_pack_len", c_size_t, [c_void_p])
+_proto("RTFilterStream_export_state", c_int, [c_void_p, c_void_p, c_void_p])
+_proto("RTFilterStream_import_state", c_int, [c_void_p, c_void_p, c_void_p])
+_proto("RTFilterStream_tail_state", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p])
+_proto("RTFilterStream_get_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
+_proto("RTFilterStream_set_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
+
 
 def fn_address(name):
     """Address of an exported function (for pointer-identity checks and struct fields)."""

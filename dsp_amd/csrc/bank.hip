@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "RTFilterBank.h"
+#include "RTFilterStream.h"
 #include "dsp_internal.h"
 
 namespace {
@@ -1078,6 +1079,334 @@ int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream)
         f->initialized = ini[c];
     }
     return RTFB_OK;
+}
+
+}  /* extern "C" */
+
+/* ======================================================================== */
+/* RTFilterStream: one filter over a very long stream, time-parallel          */
+/* (include/RTFilterStream.h; BASELINE.json config 5)                         */
+
+namespace {
+
+constexpr size_t kStreamMaxSplit = 2048;      /* sub-chunks per call at most (2 x the 1024 workgroups a GPU holds) */
+constexpr size_t kStreamMinSplit = 8;         /* below this the sequential path is as good */
+constexpr size_t kStreamGrain = 2048;         /* sub-chunk lengths are multiples of the scan segment */
+constexpr size_t kStreamMaxDecay = (size_t)1 << 20;
+constexpr long double kStreamNegligible = 0x1.0p-80L;
+
+struct SplitBanks {
+    RTFilterBank *main = nullptr;             /* C channels: the sub-chunks */
+    RTFilterBank *warm = nullptr;             /* C-1 channels: zero-state run-ups to sub-chunks 1..C-1 */
+};
+
+}  // namespace
+
+struct RTFilterStream {
+    int device = 0;
+    std::vector<double> b, a;
+    int kind = RTFB_KIND_IIR;
+    size_t decay = 0;                         /* M; 0 = no time split */
+    size_t last_split = 1;
+    RTFilterBank *one = nullptr;              /* 1 channel: owns the carried state; sequential path */
+    RTFilterBank *tail = nullptr;             /* 1 channel: RTFilterStream_tail_state */
+    std::map<size_t, SplitBanks> split;       /* by C */
+    double *d_scratch = nullptr;              /* outputs of the run-ups (discarded) */
+    size_t scratch_doubles = 0;
+};
+
+namespace {
+
+RTFilterDesign design_view(const RTFilterStream *st)
+{
+    RTFilterDesign d;
+    d.kind = st->kind;
+    d.nb = st->b.size();
+    d.na = st->a.size();
+    d.b = st->b.data();
+    d.a = st->a.empty() ? nullptr : st->a.data();
+    return d;
+}
+
+/* Smallest power of two M with max|A^M| < 2^-80 (long double, by squaring); 0 if none up to 2^20. */
+size_t decay_length(const std::vector<double> &a)
+{
+    const int N = (int)a.size() - 1;
+    if (N < 1) return 0;
+    typedef std::vector<long double> Mat;
+    Mat P((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i) {
+        P[(size_t)i * N] = -(long double)a[i + 1] / (long double)a[0];
+        if (i + 1 < N) P[(size_t)i * N + i + 1] += 1.0L;
+    }
+    for (size_t m = 1; m <= kStreamMaxDecay; m <<= 1) {
+        long double big = 0.0L;
+        for (long double v : P) big = std::max(big, std::fabs(v));
+        if (!(big == big) || big > 0x1.0p+400L) return 0;       /* unstable */
+        if (big < kStreamNegligible) return std::max<size_t>(m, 64);
+        Mat Q((size_t)N * N, 0.0L);
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < N; ++k) {
+                const long double pik = P[(size_t)i * N + k];
+                for (int j = 0; j < N; ++j) Q[(size_t)i * N + j] += pik * P[(size_t)k * N + j];
+            }
+        P.swap(Q);
+    }
+    return 0;
+}
+
+int one_channel_bank(RTFilterBank **bank, const RTFilterStream *st)
+{
+    const RTFilterDesign d = design_view(st);
+    const int32_t zero = 0;
+    return RTFilterBank_from_designs(bank, &d, 1, &zero, 1, st->device);
+}
+
+int split_banks(RTFilterStream *st, size_t C, SplitBanks **out)
+{
+    auto it = st->split.find(C);
+    if (it == st->split.end()) {
+        SplitBanks sb;
+        const RTFilterDesign d = design_view(st);
+        std::vector<int32_t> zeros(C, 0);
+        int rc = RTFilterBank_from_designs(&sb.main, &d, 1, zeros.data(), C, st->device);
+        if (rc) return rc;
+        rc = RTFilterBank_from_designs(&sb.warm, &d, 1, zeros.data(), C - 1, st->device);
+        if (rc) {
+            RTFilterBank_destroy(sb.main);
+            return rc;
+        }
+        it = st->split.emplace(C, sb).first;
+    }
+    *out = &it->second;
+    return RTFB_OK;
+}
+
+int stream_scratch(RTFilterStream *st, size_t doubles, hipStream_t s)
+{
+    if (st->scratch_doubles >= doubles) return RTFB_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    pool_free(st->d_scratch);
+    st->d_scratch = nullptr;
+    st->scratch_doubles = 0;
+    void *p = nullptr;
+    int rc = pool_alloc(&p, doubles * sizeof(double), st->device);
+    if (rc) return rc;
+    st->d_scratch = static_cast<double *>(p);
+    st->scratch_doubles = doubles;
+    return RTFB_OK;
+}
+
+/* One time-split piece: in[0 .. C*Lc) as C channels of Lc samples. */
+int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t C, size_t Lc, hipStream_t s)
+{
+    SplitBanks *sb = nullptr;
+    int rc = split_banks(st, C, &sb);
+    if (rc) return rc;
+    const size_t M = st->decay;
+    if ((rc = stream_scratch(st, (C - 1) * M, s))) return rc;
+    Group &gm = sb->main->groups[0], &gw = sb->warm->groups[0], &g1 = st->one->groups[0];
+    const size_t ld = (size_t)gm.state_ld;
+
+    /* run-ups: channel c-1 of `warm` filters the M samples in front of sub-chunk c from the zero state */
+    HIP_TRY(hipMemsetAsync(gw.d_state, 0, (C - 1) * ld * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(gw.d_init, 0, (C - 1) * sizeof(int32_t), s));
+    rc = RTFilterBank_updaten(sb->warm, st->d_scratch, M, in + (Lc - M), Lc, M, s);
+    if (rc) return rc;
+
+    /* start states: sub-chunk 0 takes the carried state, sub-chunk c the end state of run-up c-1 */
+    HIP_TRY(hipMemcpyAsync(gm.d_state, g1.d_state, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(gm.d_fval, g1.d_fval, sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(gm.d_init, 0, C * sizeof(int32_t), s));
+    HIP_TRY(hipMemcpyAsync(gm.d_init, g1.d_init, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(gm.d_state + ld, gw.d_state, (C - 1) * ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+
+    rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s);
+    if (rc) return rc;
+
+    /* the stream's state is what the last sub-chunk ended in */
+    HIP_TRY(hipMemcpyAsync(g1.d_state, gm.d_state + (C - 1) * ld, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g1.d_fval, gm.d_fval + (C - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(g1.d_init, 0, sizeof(int32_t), s));
+    return RTFB_OK;
+}
+
+int stream_create(RTFilterStream **stream, RTFilterStream *st)
+{
+    int rc = RTFB_OK;
+    if (st->kind == RTFB_KIND_IIR && !st->one->groups.empty() && st->one->groups[0].cls == kIirFast &&
+        st->one->designs[0].scan_safe() && iir_scan_supported(st->one->groups[0].order)) {
+        st->decay = decay_length(st->a);
+        if (st->decay) rc = one_channel_bank(&st->tail, st);
+    }
+    if (rc) {
+        RTFilterStream_destroy(st);
+        return rc;
+    }
+    *stream = st;
+    return RTFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int RTFilterStream_from_design(RTFilterStream **stream, const RTFilterDesign *design, int device)
+{
+    if (!stream || !design) return fail(RTFB_EINVAL, "RTFilterStream_from_design: NULL argument");
+    *stream = nullptr;
+    int rc = validate_design(*design);
+    if (rc) return rc;
+    if ((rc = check_device(device))) return rc;
+    RTFilterStream *st = new RTFilterStream;
+    st->device = device;
+    st->kind = design->kind;
+    st->b.assign(design->b, design->b + design->nb);
+    if (design->kind == RTFB_KIND_IIR) st->a.assign(design->a, design->a + design->na);
+    if ((rc = one_channel_bank(&st->one, st))) {
+        delete st;
+        return rc;
+    }
+    return stream_create(stream, st);
+}
+
+int RTFilterStream_from_filter(RTFilterStream **stream, RTFilter *filter, int device)
+{
+    if (!stream || !filter) return fail(RTFB_EINVAL, "RTFilterStream_from_filter: NULL argument");
+    *stream = nullptr;
+    RTFilterBank *one = nullptr;
+    RTFilter *const list[1] = {filter};
+    int rc = RTFilterBank_from_filters(&one, list, 1, device);
+    if (rc) return rc;
+    RTFilterStream *st = new RTFilterStream;
+    st->device = device;
+    st->one = one;
+    const Design &d = one->designs[0];
+    st->kind = d.kind;
+    st->b = d.b;
+    st->a = d.a;
+    return stream_create(stream, st);
+}
+
+void RTFilterStream_destroy(RTFilterStream *st)
+{
+    if (!st) return;
+    for (auto &kv : st->split) {
+        RTFilterBank_destroy(kv.second.main);
+        RTFilterBank_destroy(kv.second.warm);
+    }
+    RTFilterBank_destroy(st->tail);
+    RTFilterBank_destroy(st->one);             /* synchronises the device */
+    pool_free(st->d_scratch);
+    delete st;
+}
+
+size_t RTFilterStream_decay_length(const RTFilterStream *st) { return st ? st->decay : 0; }
+size_t RTFilterStream_last_split(const RTFilterStream *st) { return st ? st->last_split : 0; }
+
+int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, size_t n, void *hip_stream)
+{
+    if (!st || !out || !in) return fail(RTFB_EINVAL, "RTFilterStream_updaten: NULL argument");
+    if (n > (size_t)1 << 40) return fail(RTFB_ESIZE, "RTFilterStream_updaten: n too large");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    st->last_split = 1;
+    bool first = true;
+    while (n) {
+        /* sub-chunk: at least 4 decay lengths (the run-up costs M/Lc extra) and 8192 samples */
+        size_t lmin = std::max<size_t>(4 * st->decay, 8192);
+        lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
+        size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
+        if (C < kStreamMinSplit) {                    /* sequential: the one-channel bank itself */
+            int rc = RTFilterBank_updaten(st->one, out, n, in, n, n, s);
+            if (rc) return rc;
+            break;
+        }
+        const size_t Lc = n / C / kStreamGrain * kStreamGrain;
+        if (first) st->last_split = C;
+        first = false;
+        int rc = stream_split_piece(st, out, in, C, Lc, s);
+        if (rc) return rc;
+        out += C * Lc;
+        in += C * Lc;
+        n -= C * Lc;
+    }
+    return RTFB_OK;
+}
+
+int RTFilterStream_reset(RTFilterStream *st, void *hip_stream)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    return RTFilterBank_reset(st->one, hip_stream);
+}
+
+int RTFilterStream_sync_to_host(RTFilterStream *st, void *hip_stream)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    return RTFilterBank_sync_to_host(st->one, hip_stream);
+}
+
+size_t RTFilterStream_pack_len(const RTFilterStream *st)
+{
+    return st ? (size_t)st->one->groups[0].state_ld + 2 : 0;
+}
+
+int RTFilterStream_export_state(RTFilterStream *st, double *pack_dev, void *hip_stream)
+{
+    if (!st || !pack_dev) return fail(RTFB_EINVAL, "RTFilterStream_export_state: NULL argument");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    const Group &g = st->one->groups[0];
+    HIP_TRY(launch_state_pack(pack_dev, g.d_state, g.d_fval, g.d_init, g.state_ld,
+                              static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int RTFilterStream_import_state(RTFilterStream *st, const double *pack_dev, void *hip_stream)
+{
+    if (!st || !pack_dev) return fail(RTFB_EINVAL, "RTFilterStream_import_state: NULL argument");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    const Group &g = st->one->groups[0];
+    HIP_TRY(launch_state_unpack(pack_dev, g.d_state, g.d_fval, g.d_init, g.state_ld,
+                                static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int RTFilterStream_tail_state(RTFilterStream *st, const double *in, size_t n, double *pack_dev,
+                              void *hip_stream)
+{
+    if (!st || !in || !pack_dev) return fail(RTFB_EINVAL, "RTFilterStream_tail_state: NULL argument");
+    if (!st->decay || !st->tail)
+        return fail(RTFB_EUNSUPPORTED, "RTFilterStream_tail_state: the design does not decay; chain the true end states");
+    if (n < st->decay)
+        return fail(RTFB_EUNSUPPORTED, "RTFilterStream_tail_state: chunk shorter than the decay length");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t M = st->decay;
+    int rc = stream_scratch(st, std::max<size_t>(M, 1), s);
+    if (rc) return rc;
+    const Group &g = st->tail->groups[0];
+    HIP_TRY(hipMemsetAsync(g.d_state, 0, (size_t)g.state_ld * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.d_init, 0, sizeof(int32_t), s));
+    if ((rc = RTFilterBank_updaten(st->tail, st->d_scratch, M, in + (n - M), M, M, s))) return rc;
+    HIP_TRY(launch_state_pack(pack_dev, g.d_state, g.d_fval, g.d_init, g.state_ld, s));
+    return RTFB_OK;
+}
+
+int RTFilterStream_get_state(RTFilterStream *st, double *state, double *fval, int32_t *init, void *hip_stream)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    return RTFilterBank_get_state(st->one, state, fval, init, hip_stream);
+}
+
+int RTFilterStream_set_state(RTFilterStream *st, const double *state, const double *fval, const int32_t *init,
+                             void *hip_stream)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    return RTFilterBank_set_state(st->one, state, fval, init, hip_stream);
 }
 
 }  /* extern "C" */

@@ -86,6 +86,10 @@ hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t s
 
 hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
                             size_t n, int threads, int seg, hipStream_t s);
+hipError_t launch_state_pack(double *pack, const double *state, const double *fval, const int32_t *init,
+                             int ld, hipStream_t s);
+hipError_t launch_state_unpack(const double *pack, double *state, double *fval, int32_t *init, int ld,
+                               hipStream_t s);
 bool iir_scan_supported(int order);
 
 }  // namespace dsp

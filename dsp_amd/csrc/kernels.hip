@@ -486,6 +486,28 @@ __global__ void reset_kernel(GroupView g)
     }
 }
 
+/* State hand-off vector of RTFilterStream: state[0..ld), filtered_value, (double)initialized. */
+__global__ void state_pack_kernel(double *pack, const double *state, const double *fval, const int32_t *init,
+                                  int ld)
+{
+    const int i = threadIdx.x;
+    if (i < ld) pack[i] = state[i];
+    if (i == 0) {
+        pack[ld] = fval[0];
+        pack[ld + 1] = (double)init[0];
+    }
+}
+
+__global__ void state_unpack_kernel(const double *pack, double *state, double *fval, int32_t *init, int ld)
+{
+    const int i = threadIdx.x;
+    if (i < ld) state[i] = pack[i];
+    if (i == 0) {
+        fval[0] = pack[ld];
+        init[0] = (int32_t)pack[ld + 1];
+    }
+}
+
 /* Synthetic input generator; two samples per thread. */
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 {
@@ -621,6 +643,21 @@ hipError_t launch_reset(const GroupView &g, hipStream_t s)
 {
     const int blocks = (g.count + 255) / 256;
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_pack(double *pack, const double *state, const double *fval, const int32_t *init,
+                             int ld, hipStream_t s)
+{
+    hipLaunchKernelGGL(state_pack_kernel, dim3(1), dim3(((ld + 63) / 64) * 64), 0, s, pack, state, fval, init, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_unpack(const double *pack, double *state, double *fval, int32_t *init, int ld,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(state_unpack_kernel, dim3(1), dim3(((ld + 63) / 64) * 64), 0, s, pack, state, fval, init,
+                       ld);
     return hipGetLastError();
 }
 

@@ -1,0 +1,85 @@
+/*
+ * RTFilterStream.h -- additive MI355X (gfx950) API of libdsp: ONE RTFilter advanced over a
+ * very long device-resident sample stream, time-parallel.
+ *
+ * Replaces the reference call
+ *     RTFilter_updaten(out, filter, in, n)              (ref: include/RTFilter.h:89,
+ *                                                         src/RTFilter.c:111-119)
+ * for one filter and a huge n (BASELINE.json config 5: 2^30 samples, 16th-order IIR), which the
+ * reference can only run sample after sample on one core.
+ *
+ * How: the stream is cut into C consecutive sub-chunks that are filtered as the C channels of an
+ * RTFilterBank (row pitch = sub-chunk length, i.e. the stream itself, no copy).  The start state of
+ * sub-chunk c is the zero-state response of the M samples in front of it, where M is the design's
+ * decay length: the smallest power of two with max|A^M| < 2^-80 for the homogeneous recurrence
+ * s' = A s of RTIIRFilter_update (ref: src/RTFilter.c:417-433).  What the truncation drops is
+ * below 2^-80 of the state, far inside the 1e-12 bar.  Designs that do not decay within 2^20
+ * samples, or fail the scan conditioning probe, or calls too short to split, run as a
+ * one-channel RTFilterBank instead (correct, one workgroup: not time-parallel across the GPU).  FIR designs need none of this (their
+ * bank kernels already split time) and go straight to a one-channel bank.
+ *
+ * Across GPUs (one process per GPU, rank r owns samples [r L, (r+1) L)): every rank but the last
+ * computes RTFilterStream_tail_state of its own chunk -- the state hand-off vector, N+3 doubles --
+ * and sends it to rank r+1 (RCCL/xGMI send-recv or all_gather), which imports it and runs
+ * RTFilterStream_updaten on its chunk.  All ranks then filter concurrently.
+ *
+ * Plain C ABI: opaque handle, raw device pointers, sizes, int status (RTFB_* of RTFilterBank.h).
+ */
+#ifndef RTFILTERSTREAM_H
+#define RTFILTERSTREAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "RTFilterBank.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RTFilterStream RTFilterStream;
+
+/* A stream filter in the state RT{IIR,FIR}Filter_init leaves (state zero, initialized = FILTER_RESET). */
+EXPORT int RTFilterStream_from_design(RTFilterStream **stream, const RTFilterDesign *design, int device);
+/* From a host filter (library callbacks only, else RTFB_EUNSUPPORTED): coefficients and the CURRENT
+ * state / filtered_value / initialized are copied; the pointer is kept for _sync_to_host. */
+EXPORT int RTFilterStream_from_filter(RTFilterStream **stream, RTFilter *filter, int device);
+EXPORT void RTFilterStream_destroy(RTFilterStream *stream);
+
+/* == RTFilter_updaten(out, filter, in, n) with DEVICE pointers; in == out allowed; enqueues on
+ * `hip_stream` (a hipStream_t, NULL = default) and returns.  State carries to the next call. */
+EXPORT int RTFilterStream_updaten(RTFilterStream *stream, double *out, const double *in, size_t n,
+                                  void *hip_stream);
+/* RTFilter_reset (src/RTFilter.c:55-58): initialized = FILTER_RESET, state untouched. */
+EXPORT int RTFilterStream_reset(RTFilterStream *stream, void *hip_stream);
+/* Host structs given to _from_filter take state, filtered_value, initialized.  Synchronises. */
+EXPORT int RTFilterStream_sync_to_host(RTFilterStream *stream, void *hip_stream);
+
+/* Decay length M in samples; 0 = the design does not qualify for the time split. */
+EXPORT size_t RTFilterStream_decay_length(const RTFilterStream *stream);
+/* Sub-chunks the last _updaten call used for its largest piece (1 = sequential path); diagnostics. */
+EXPORT size_t RTFilterStream_last_split(const RTFilterStream *stream);
+
+/* ---- state hand-off (device side) --------------------------------------------------------
+ * A hand-off vector is RTFilterStream_pack_len() doubles in device memory:
+ *   state[0 .. state_ld), filtered_value, (double)initialized. */
+EXPORT size_t RTFilterStream_pack_len(const RTFilterStream *stream);
+EXPORT int RTFilterStream_export_state(RTFilterStream *stream, double *pack_dev, void *hip_stream);
+EXPORT int RTFilterStream_import_state(RTFilterStream *stream, const double *pack_dev, void *hip_stream);
+/* The hand-off vector a filter would hold after in[0..n) to within 2^-80 of its state, computed
+ * from the last min(n, M) samples alone (zero-state response); does not touch the stream's own
+ * state.  RTFB_EUNSUPPORTED when the design does not decay (decay_length == 0) or n < M: the
+ * caller must then chain the ranks one after another with export/import of the true end state. */
+EXPORT int RTFilterStream_tail_state(RTFilterStream *stream, const double *in, size_t n,
+                                     double *pack_dev, void *hip_stream);
+
+/* Host access to the carried state (state_ld doubles, see RTFilterStream_pack_len() - 2). */
+EXPORT int RTFilterStream_get_state(RTFilterStream *stream, double *state, double *fval, int32_t *init,
+                                    void *hip_stream);
+EXPORT int RTFilterStream_set_state(RTFilterStream *stream, const double *state, const double *fval,
+                                    const int32_t *init, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RTFILTERSTREAM_H */

@@ -1,0 +1,160 @@
+"""RTFilterStream (include/RTFilterStream.h) against the oracle: one filter, one long stream, split in
+time on the GPU (BASELINE.json config 5's single-GPU leg), plus the state hand-off entry points the
+multi-GPU split uses.  Tolerance: 1e-12 relative to the output peak (north star)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _bw8():
+    _, b, a = util.design_coefs("bw8_bp_0.25_0.75")   # order 16: config 5's filter
+    return b, a
+
+
+def _designs():
+    _, b4, a4 = util.design_coefs("bw4_bp_0.3_0.6")
+    b8, a8 = _bw8()
+    return {"bw4": (b4, a4), "bw8": (b8, a8)}
+
+
+@pytest.mark.parametrize("name", ["bw4", "bw8"])
+@pytest.mark.parametrize("blocks", [[1 << 20], [300000, 5, 700001, 40000]])
+def test_stream_updaten_matches_oracle(G, name, blocks):
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _designs()[name]
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    assert fs.decay_length > 0
+    ref = orc.iir(b, a)
+    pos = 0
+    for n in blocks:
+        x = util.synth(11, 3, pos, n)
+        xd = torch.from_numpy(x).cuda()
+        yd = fs(xd)
+        torch.cuda.synchronize()
+        want = ref.updaten(x)
+        err = np.max(np.abs(yd.cpu().numpy() - want)) / np.max(np.abs(want))
+        assert err <= TOL, (name, n, err)
+        if n >= 300000:
+            assert fs.last_split >= 8        # really went through the time split
+        pos += n
+    st, fv, ini = fs.get_state()
+    assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+    assert abs(fv - ref.filtered_value) <= TOL * max(1.0, abs(ref.filtered_value))
+    assert ini == ref.initialized == 0
+    fs.close()
+
+
+def test_stream_in_place_and_reset(G):
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _designs()["bw4"]
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    ref = orc.iir(b, a)
+    for rep in range(2):
+        x = util.synth(5, 0, 0, 400000)
+        xd = torch.from_numpy(x).cuda()
+        fs(xd, out=xd)
+        torch.cuda.synchronize()
+        want = ref.updaten(x)
+        assert np.max(np.abs(xd.cpu().numpy() - want)) <= TOL * np.max(np.abs(want))
+        fs.reset()                            # RTFilter_reset: the stale state stays (ref :55-58)
+        ref.reset()
+    fs.close()
+
+
+def test_stream_short_and_fir_paths(G):
+    """Calls too short to split and FIR designs run as a one-channel bank."""
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _designs()["bw4"]
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    ref = orc.iir(b, a)
+    x = util.synth(1, 0, 0, 5000)
+    y = fs(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ref.updaten(x)
+    assert fs.last_split == 1
+    assert np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+    fs.close()
+    _, bf, _ = util.design_coefs("fir512_lp_0.25")
+    ff = gstream.FilterStream(gbank.fir_design(bf))
+    assert ff.decay_length == 0
+    rf = orc.fir(bf)
+    x = util.synth(2, 0, 0, 300000)
+    y = ff(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = rf.updaten(x)
+    assert np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+    ff.close()
+
+
+def test_tail_state_handoff_equals_one_long_run(G):
+    """The multi-GPU protocol on one GPU: two FilterStream objects play rank 0 and rank 1."""
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _designs()["bw8"]
+    n = 1 << 19
+    x = util.synth(9, 0, 0, 2 * n)
+    xd = torch.from_numpy(x).cuda()
+    r0 = gstream.FilterStream(gbank.iir_design(b, a))
+    r1 = gstream.FilterStream(gbank.iir_design(b, a))
+    pack = r0.new_pack()
+    assert r0.tail_state(xd[:n], pack)        # rank 0: hand-off vector of its own chunk
+    r1.import_state(pack)                     # rank 1 starts from it ...
+    y1 = r1(xd[n:])                           # ... and both filter concurrently
+    y0 = r0(xd[:n])
+    torch.cuda.synchronize()
+    want = orc.iir(b, a).updaten(x)
+    got = np.concatenate([y0.cpu().numpy(), y1.cpu().numpy()])
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    # chunk shorter than the decay length: the shortcut is refused, the caller chains
+    assert not r0.tail_state(xd[:r0.decay_length - 1], pack)
+    # export/import of the true state
+    r0.export_state(pack)
+    r1.import_state(pack)
+    s0, s1 = r0.get_state(), r1.get_state()
+    assert util.bits_equal(s0[0], s1[0]) and s0[1:] == s1[1:]
+    r0.close()
+    r1.close()
+
+
+def test_stream_from_filter_and_sync_to_host(G):
+    import torch
+    from dsp_amd import dsp
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    f = dsp.butterworth(4, 0.3, 0.6)
+    b, a = np.array(f.b(), dtype=np.float64), np.array(f.a(), dtype=np.float64)
+    ref = orc.iir(b, a)
+    head = util.synth(3, 0, 0, 1000)
+    f(list(head))                             # host filter advances first; the stream takes its state over
+    ref.updaten(head)
+    fs = gstream.FilterStream.from_filter(f)
+    x = util.synth(3, 0, 1000, 500000)
+    y = fs(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ref.updaten(x)
+    assert np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+    fs.sync_to_host()
+    assert np.max(np.abs(np.array(f.state()) - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+    assert f.initialized == 0
+    fs.close()

@@ -30,7 +30,7 @@ def test_struct_layouts_match_reference_abi():
 
 def test_every_declared_symbol_is_exported():
     names = set()
-    for hdr in ("RTFilter.h", "RTFilterBank.h"):
+    for hdr in ("RTFilter.h", "RTFilterBank.h", "RTFilterStream.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"EXPORT\s+[\w\s\*]+?\b(\w+)\s*\(", text))
@@ -200,4 +200,8 @@ def test_device_api_fails_loudly_without_a_gpu():
     _, b, a = util.design_coefs("bw4_bp_0.3_0.6")
     with pytest.raises(gbank.DSPError) as ei:
         gbank.FilterBank([gbank.iir_design(b, a)], [0, 0])
+    assert ei.value.status == cdsp.RTFB_EDEVICE
+    from dsp_amd import stream as gstream
+    with pytest.raises(gbank.DSPError) as ei:
+        gstream.FilterStream(gbank.iir_design(b, a))
     assert ei.value.status == cdsp.RTFB_EDEVICE
