@@ -85,12 +85,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", choices=["auto", "scan", "seq"], default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--workload", choices=["iir8", "fir512"], default="iir8",
-                    help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3")
+    ap.add_argument("--workload", choices=["iir8", "fir512", "stream16"], default="iir8",
+                    help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3; "
+                         "stream16 = config 5 (one 2^30-sample stream, 16th-order IIR, split in time)")
+    ap.add_argument("--stream-log2", type=int, default=30)
     ap.add_argument("--fir-channels", type=int, default=65536)
     args = ap.parse_args()
     if args.workload == "fir512":
         return main_fir512(args)
+    if args.workload == "stream16":
+        return main_stream16(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +287,109 @@ def main_fir512(args):
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_fir(b)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_stream16(args):
+    """BASELINE.json config 5: ONE 2^30-sample stream through a 16th-order IIR (butterworth(8, 0.25, 0.75),
+    na = nb = 17).  One STEP = RTFilter_updaten over the whole stream: on N GPUs rank r holds samples
+    [r L, (r+1) L) resident, the ranks exchange the state hand-off vectors (dsp_amd.stream.split_update:
+    one all_gather of 19 doubles per rank + the end-state broadcast, RCCL over xGMI) and filter their
+    chunks concurrently => STRONG scaling (total work fixed).  Consecutive steps continue the stream."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from tests import util
+    _, b, a = util.design_coefs("bw8_bp_0.25_0.75")
+    total = 1 << args.stream_log2
+    lo, hi = gstream.time_range(total, world, rank)
+    n = hi - lo
+    fs = gstream.FilterStream(gbank.iir_design(b, a), device=local)
+    x = torch.empty((1, n), dtype=torch.float64, device=dev)
+    gbank.synth_fill(x, SEED, chan0=0, n0=lo)
+    x = x.view(-1)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        if world > 1:
+            gstream.split_update(fs, x, y, stream=stream)
+        else:
+            fs(x, y, stream)
+        if ev is not None:
+            ev[1].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    avg_s = float(np.mean(step_ms)) / 1e3
+    if rank == 0:
+        achieved = n * BYTES_PER_SAMPLE / avg_s / 1e9
+        line = {
+            "metric": "filtered Msamples/s (whole node)", "value": total * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 5: single 2^%d-sample stream, 16th-order IIR (butterworth(8,0.25,0.75)), "
+                                   "chunked state-space scan split in time, state hand-off between chunks"
+                                   % args.stream_log2,
+                       "samples_per_gpu": n, "sub_chunks": fs.last_split, "decay_length": fs.decay_length,
+                       "parallelism": "time-split x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
+                         "note": "per-GPU bytes of one step over the step's device time on rank 0 (run-ups and "
+                                 "hand-off included)",
+                         "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import oracle as orc
+            from oracle import ref
+            m = 1 << 24                                   # one core: the path is serial on the CPU
+            xs = util.synth(SEED, 0, 0, m)
+            kind = "reference" if ref.available() else "port"
+            f = ref.RefIIR(b, a) if kind == "reference" else orc.iir(b, a)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 10.0:
+                f.updaten(xs)
+                reps += 1
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = dict(value=reps * m / dt / 1e6, unit="Msamples/s", cores=1, kind=kind,
+                                        sample="%d x 2^24 consecutive samples of the config-5 stream on one host core "
+                                               "(one filter is serial in time on the CPU), %.1f s" % (reps, dt))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -149,27 +149,39 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None):
     if world == 1:
         return engine(x_local, out_local, stream)
 
+    # gloo (the CPU tests, or a rehearsal with several ranks on one GPU) moves host tensors only:
+    # stage the few doubles of the hand-off through the host there; RCCL takes the device tensors.
+    host_hop = dist.get_backend(group) == "gloo"
+
+    def wire(t):
+        return t.cpu() if (host_hop and t.is_cuda) else t
+
+    def peer(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+
     pack = engine.new_pack()
     ok = engine.tail_state(x_local, pack, stream) if x_local.numel() else False
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=pack.device)
+    flag = wire(torch.tensor([1 if ok else 0], dtype=torch.int32, device=pack.device))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if int(flag.item()) == 1:
-        packs = [torch.empty_like(pack) for _ in range(world)]
-        dist.all_gather(packs, pack, group=group)
+        mine = wire(pack)
+        packs = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(packs, mine, group=group)
         if rank > 0:
-            engine.import_state(packs[rank - 1], stream)
+            engine.import_state(packs[rank - 1].to(pack.device), stream)
         out = engine(x_local, out_local, stream)
     else:
         if rank > 0:
-            dist.recv(pack, src=dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group=group)
-            engine.import_state(pack, stream)
+            got = wire(pack)
+            dist.recv(got, src=peer(rank - 1), group=group)
+            engine.import_state(got.to(pack.device), stream)
         out = engine(x_local, out_local, stream)
         if rank < world - 1:
             engine.export_state(pack, stream)
-            dist.send(pack, dst=dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group=group)
+            dist.send(wire(pack), dst=peer(rank + 1), group=group)
     # everyone ends with the stream's end state (the last rank's true state)
     engine.export_state(pack, stream)
-    last = dist.get_global_rank(group, world - 1) if group is not None else world - 1
-    dist.broadcast(pack, src=last, group=group)
-    engine.import_state(pack, stream)
+    last = wire(pack)
+    dist.broadcast(last, src=peer(world - 1), group=group)
+    engine.import_state(last.to(pack.device), stream)
     return out

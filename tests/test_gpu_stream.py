@@ -158,3 +158,60 @@ def test_stream_from_filter_and_sync_to_host(G):
     assert np.max(np.abs(np.array(f.state()) - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
     assert f.initialized == 0
     fs.close()
+
+
+def _rank_worker(rank, world, port, n, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, a = _bw8()
+        fs = gstream.FilterStream(gbank.iir_design(b, a), device=0)
+        outs = []
+        for blk in range(2):
+            lo, hi = gstream.time_range(n, world, rank)
+            x = torch.from_numpy(util.synth(21, 0, blk * n + lo, hi - lo)).cuda()
+            y = gstream.split_update(fs, x)
+            torch.cuda.synchronize()
+            parts = [None] * world
+            dist.all_gather_object(parts, y.cpu().numpy())
+            outs.append(np.concatenate(parts))
+        st = fs.get_state()[0]
+        if rank == 0:
+            q.put((np.concatenate(outs), st))
+        fs.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_split_the_stream(G):
+    """Rehearsal of the multi-GPU leg: two processes (gloo for the hand-off, both on cuda:0) each own
+    half of every block of the stream; the result equals one long run of the reference."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    n, world = (1 << 20) + 4096, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, st = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, a = _bw8()
+    ref = orc.iir(b, a)
+    want = ref.updaten(util.synth(21, 0, 0, 2 * n))
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
