@@ -191,6 +191,8 @@ struct Design {
     int levels2 = 0;
     int gtab_off = 0;
     int ttab_off = -1;
+    int levels1 = kScanLevels;
+    int gtab1_off = 0;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
     bool scan_safe() const;
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
@@ -240,6 +242,7 @@ struct RTFilterBank {
     size_t state_ld = 1;                /* uniform ld of the get/set_state API */
     /* device tables shared by all groups */
     int32_t *d_coef_off = nullptr, *d_pow_off = nullptr, *d_pow2_off = nullptr, *d_levels2 = nullptr, *d_gtab_off = nullptr, *d_ttab_off = nullptr,
+            *d_levels1 = nullptr, *d_gtab1_off = nullptr,
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
 };
@@ -342,10 +345,10 @@ void pipe_ttable(const Design &d, int T, std::vector<double> &out)
 constexpr double kScan2Negligible = 0x1.0p-75;
 constexpr size_t kMaxPipeDesigns = 1024;     /* 64 propagators of N x N doubles per design */
 
-int scan2_levels(const double *pw, int N)
+int scan2_levels(const double *pw, int N, int nlevels = kScan2Levels)
 {
     int need = 0;
-    for (int lvl = 0; lvl < kScan2Levels; ++lvl) {
+    for (int lvl = 0; lvl < nlevels; ++lvl) {
         double m = 0.0;
         for (int e = 0; e < N * N; ++e) {
             const double v = std::fabs(pw[(size_t)lvl * N * N + e]);
@@ -460,6 +463,8 @@ void free_bank_device(RTFilterBank *b)
     pool_free(b->d_pow2_off);
     pool_free(b->d_levels2);
     pool_free(b->d_gtab_off);
+    pool_free(b->d_levels1);
+    pool_free(b->d_gtab1_off);
     pool_free(b->d_ttab_off);
     pool_free(b->d_nb);
     pool_free(b->d_na);
@@ -479,7 +484,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
 
     /* design tables */
-    std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, nb, na, kind;
+    std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, levels1, gtab1_off, nb, na, kind;
     std::vector<double> coefs, pows;
     size_t ld = 1;
     for (Design &d : bk->designs) {
@@ -491,6 +496,9 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             scan_powers(d, kScanT, kScanLevels, pows);
             const std::vector<double> mine(pows.begin() + d.pow_off, pows.end());
             d.scan_error = scan_probe(d, mine);
+            d.levels1 = scan2_levels(&pows[d.pow_off], d.nb - 1, kScanLevels);
+            d.gtab1_off = (int)pows.size();
+            scan2_gtable(d, kScanT, pows);
             d.pow2_off = (int)pows.size();
             scan_powers(d, kScan2T, kScan2Levels, pows);
             d.levels2 = scan2_levels(&pows[d.pow2_off], d.nb - 1);
@@ -503,6 +511,8 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         }
         gtab_off.push_back(d.gtab_off);
         ttab_off.push_back(d.ttab_off);
+        levels1.push_back(d.levels1);
+        gtab1_off.push_back(d.gtab1_off);
         pow2_off.push_back(d.pow2_off);
         levels2.push_back(d.levels2);
         coef_off.push_back(d.coef_off);
@@ -547,6 +557,8 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if ((rc = upload(&bk->d_pow2_off, pow2_off, device))) return rc;
     if ((rc = upload(&bk->d_levels2, levels2, device))) return rc;
     if ((rc = upload(&bk->d_gtab_off, gtab_off, device))) return rc;
+    if ((rc = upload(&bk->d_levels1, levels1, device))) return rc;
+    if ((rc = upload(&bk->d_gtab1_off, gtab1_off, device))) return rc;
     if ((rc = upload(&bk->d_ttab_off, ttab_off, device))) return rc;
     if ((rc = upload(&bk->d_nb, nb, device))) return rc;
     if ((rc = upload(&bk->d_na, na, device))) return rc;
@@ -610,6 +622,8 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.pow2_off = bk->d_pow2_off;
     v.levels2 = bk->d_levels2;
     v.gtab_off = bk->d_gtab_off;
+    v.levels1 = bk->d_levels1;
+    v.gtab1_off = bk->d_gtab1_off;
     v.ttab_off = bk->d_ttab_off;
     v.levels2_max = g.levels2_max;
     v.nb = bk->d_nb;
@@ -1317,7 +1331,9 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         /* sub-chunk: at least 4 decay lengths (the run-up costs M/Lc extra) and 8192 samples */
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
-        size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
+        static const size_t max_split =                       /* DSP_AMD_STREAM_SPLIT: A/B switch for profiling */
+            std::getenv("DSP_AMD_STREAM_SPLIT") ? (size_t)std::atoll(std::getenv("DSP_AMD_STREAM_SPLIT")) : kStreamMaxSplit;
+        size_t C = st->decay ? std::min(max_split, n / lmin) : 0;
         if (C < kStreamMinSplit) {                    /* sequential: the one-channel bank itself */
             int rc = RTFilterBank_updaten(st->one, out, n, in, n, n, s);
             if (rc) return rc;

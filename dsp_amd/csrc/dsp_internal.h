@@ -57,6 +57,9 @@ struct GroupView {
     const int32_t *gtab_off;  /* per design: offset in pows of G[n][i] = (A^(31-n) B)_i, n < 32,
                                  followed by Gc[i] = (sum_m A^m e_{N-1})_i                  */
     int32_t        levels2_max;   /* largest levels2 in the group                          */
+    const int32_t *levels1;   /* per design: combine levels of the one-wave kernel (A^(64 2^k)) that matter */
+    const int32_t *gtab1_off; /* per design: offset in pows of the one-wave kernel's zero-state table:
+                                 G[n][i] = (A^(63-n) B)_i, n < 64, followed by Gc[i]            */
     const int32_t *nb;        /* per design                                               */
     const int32_t *na;        /* per design                                               */
     const int32_t *kind;      /* per design: RTFB_KIND_*                                  */

@@ -173,7 +173,7 @@ iir_seq_kernel(GroupView g, BlockIO io)
 template <int N, int T, bool kUnitA0, bool kGeneral, bool kStamp>
 __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, bool do_seed,
                                              const double (&b)[N + 1], const double (&a)[N + 1],
-                                             cdouble_p pw,
+                                             cdouble_p pw, cdouble_p gtab, int nlev,
                                              double (&carry)[N + 1], double &ylast,
                                              unsigned long long (&acc_t)[6],
                                              unsigned long long &t_prev)
@@ -202,26 +202,27 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
     /* ---- pass 1 ---- */
     double v[N + 1];
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = (lane == 0) ? carry[i] : 0.0;
+    for (int i = 0; i < N; ++i) v[i] = (kGeneral && lane == 0) ? carry[i] : 0.0;
     v[N] = tail;
     if (kGeneral) {
         int k = 0;
         if (seed_here) { (void)iir_seed_ref<N>(*reinterpret_cast<double *>(row), v, b, a); k = 1; }
         for (; k < cnt; ++k) (void)iir_step_fused<N, kUnitA0>(*reinterpret_cast<double *>(row + k * 8), v, b, a);
     } else {
-        d2 cur0 = *reinterpret_cast<const d2 *>(row);
-        d2 cur1 = *reinterpret_cast<const d2 *>(row + 16);
-#pragma unroll 1
-        for (int k = 0; k < T; k += 4) {
-            const int kn = (k + 4 < T) ? k + 4 : k;         /* last round re-reads itself */
-            const d2 nxt0 = *reinterpret_cast<const d2 *>(row + kn * 8);
-            const d2 nxt1 = *reinterpret_cast<const d2 *>(row + kn * 8 + 16);
-            iir_step_fused<N, kUnitA0>(cur0.x, v, b, a);
-            iir_step_fused<N, kUnitA0>(cur0.y, v, b, a);
-            iir_step_fused<N, kUnitA0>(cur1.x, v, b, a);
-            iir_step_fused<N, kUnitA0>(cur1.y, v, b, a);
-            cur0 = nxt0;
-            cur1 = nxt1;
+        /* full segment: every lane's zero-state end vector from the per-design response table
+         * G[n] = A^(T-1-n) B (N FMAs per sample, scalar-loaded operands, instead of the 2N+1 of the
+         * recurrence); the carried state enters the combine as a virtual row -1 */
+#pragma unroll 2
+        for (int k = 0; k < T; k += 2) {
+            const d2 xv = *reinterpret_cast<const d2 *>(row + k * 8);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[k * N + i], xv.x, v[i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[(k + 1) * N + i], xv.y, v[i]);
+        }
+        if (tail != 0.0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[T * N + i], tail, v[i]);
         }
     }
 
@@ -229,12 +230,20 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
     /* ---- prefix combine across lanes: v_j <- end state after lane j ---- */
 #pragma unroll
     for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+        /* levels whose matrix A^(T 2^lvl) has decayed below 2^-75 add nothing (decided per design on
+         * the host); ragged / seeded segments keep all of them */
+        if (!kGeneral && lvl >= nlev) break;
         const int d = 1 << lvl;
         double u[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] = shfl_up_f64(v[i], d);
+        const bool inject = !kGeneral && lane == d - 1;     /* virtual row -1 = the carried state */
+        if (inject) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) u[i] = carry[i];
+        }
         cdouble_p M = pw + lvl * N * N;
-        if (lane >= d) {                       /* lanes below d keep their value (exec-masked) */
+        if (lane >= d || inject) {             /* lanes below d keep their value (exec-masked) */
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 double acc = v[i];
@@ -321,6 +330,8 @@ iir_scan_kernel(GroupView g, BlockIO io)
         for (int i = 0; i <= N; ++i) carry[i] = st[i];
     }
     cdouble_p pw = as_const(g.pows) + as_const(g.pow_off)[dsn];
+    cdouble_p gtab = as_const(g.pows) + as_const(g.gtab1_off)[dsn];
+    const int nlev = as_const(g.levels1)[dsn];
     double ylast = g.fval[gi];
     bool need_seed = g.init[gi] != 0;
 
@@ -377,10 +388,10 @@ iir_scan_kernel(GroupView g, BlockIO io)
         stamp(1);
 
         if (seg_len == kSeg && !need_seed)
-            scan_segment<N, T, kUnitA0, false, kStamp>(smem, lane, seg_len, false, b, a, pw, carry,
+            scan_segment<N, T, kUnitA0, false, kStamp>(smem, lane, seg_len, false, b, a, pw, gtab, nlev, carry,
                                                        ylast, acc_t, t_prev);
         else
-            scan_segment<N, T, kUnitA0, true, kStamp>(smem, lane, seg_len, need_seed, b, a, pw, carry,
+            scan_segment<N, T, kUnitA0, true, kStamp>(smem, lane, seg_len, need_seed, b, a, pw, gtab, nlev, carry,
                                                       ylast, acc_t, t_prev);
         need_seed = false;
         wave_sync();
