@@ -85,16 +85,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", choices=["auto", "scan", "seq"], default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--workload", choices=["iir8", "fir512", "stream16"], default="iir8",
+    ap.add_argument("--workload", choices=["iir8", "fir512", "stream16", "mixed"], default="iir8",
                     help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3; "
                          "stream16 = config 5 (one 2^30-sample stream, 16th-order IIR, split in time)")
     ap.add_argument("--stream-log2", type=int, default=30)
+    ap.add_argument("--mixed-channels", type=int, default=131072,
+                    help="config 4: channels per GPU (2^20 over 8 GPUs)")
+    ap.add_argument("--gather", action="store_true",
+                    help="config 4: all_gather every channel's filtered_value after each block (RCCL)")
     ap.add_argument("--fir-channels", type=int, default=65536)
     args = ap.parse_args()
     if args.workload == "fir512":
         return main_fir512(args)
     if args.workload == "stream16":
         return main_stream16(args)
+    if args.workload == "mixed":
+        return main_mixed(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -287,6 +293,99 @@ def main_fir512(args):
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_fir(b)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_mixed(args):
+    """BASELINE.json config 4: 2^20-channel mixed FIR/IIR bank x 64K samples, channel-sharded: every GPU
+    owns 131 072 channels (2^20 at 8 GPUs => WEAK scaling), interleaved designs
+      c % 4 == 0: IIR order 8 (butterworth(4,0.3,0.6))      c % 4 == 1: IIR order 16 (butterworth(8,0.25,0.75))
+      c % 4 == 2: FIR 32 taps (windowed sinc 0.25)          c % 4 == 3: IIR order 5 (butterworth(5, lp 0.25))
+    so every kernel group addresses its channels through a gather list.  One STEP = one
+    RTFilterBank_updaten over the 64K-sample block of all the rank's channels (64 GiB read + 64 GiB
+    written); consecutive steps continue the streams.  With --gather the ranks all_gather the
+    filtered_value of every channel after each block (the real-time consumer's view; 8 MiB at 2^20
+    channels) -- the sample blocks themselves stay sharded (they would not fit one GPU)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from dsp_amd import bank as gbank
+    from tests import util
+    nch = args.mixed_channels
+    keys = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "fir32_lp_0.25", "bw5_lp_0.25"]
+    designs = []
+    for k in keys:
+        kind, b, a = util.design_coefs(k)
+        designs.append(gbank.fir_design(b) if k.startswith("fir") else gbank.iir_design(b, a))
+    mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_SCAN, seq=gbank.MODE_SEQUENTIAL)[args.mode]
+    bank = gbank.FilterBank(designs, [(rank * nch + c) % 4 for c in range(nch)], device=local, mode=mode)
+    pitch = BLOCK + 128
+    xbuf = torch.empty((nch, pitch), dtype=torch.float64, device=dev)
+    ybuf = torch.empty((nch, pitch), dtype=torch.float64, device=dev)
+    x, y = xbuf[:, :BLOCK], ybuf[:, :BLOCK]
+    gbank.synth_fill(x, SEED, chan0=rank * nch, n0=0)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    fv_all = torch.empty(world * nch, dtype=torch.float64, device=dev) if (dist is not None and args.gather) else None
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        bank.updaten_ptr(y.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if fv_all is not None:
+            dist.all_gather_into_tensor(fv_all, y[:, BLOCK - 1].contiguous())
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    avg_s = float(np.mean(step_ms)) / 1e3
+    if rank == 0:
+        samples = nch * BLOCK
+        achieved = samples * BYTES_PER_SAMPLE / avg_s / 1e9
+        line = {
+            "metric": "filtered Msamples/s (whole node)", "value": world * samples * args.steps / elapsed / 1e6,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 4: mixed FIR/IIR bank (IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved), "
+                                   "%d channels per GPU x 64K samples, channel-sharded" % nch,
+                       "channels_per_gpu": nch, "block": BLOCK, "row_pitch_doubles": pitch, "kernel": args.mode,
+                       "gather": bool(fv_all is not None), "parallelism": "channel-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
+                         "note": "all kernels of one RTFilterBank_updaten (4 groups) over the call's device time",
+                         "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
+        }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -951,7 +951,9 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
                 fio.in = g.d_scratch;
                 fio.ld_in = n;
             }
-            v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= kFirMfmaMinTaps) ? 1 : 0;
+            static const int mfma_min =                       /* DSP_AMD_FIR_MFMA_MIN: A/B switch for profiling */
+                std::getenv("DSP_AMD_FIR_MFMA_MIN") ? std::atoi(std::getenv("DSP_AMD_FIR_MFMA_MIN")) : kFirMfmaMinTaps;
+            v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= mfma_min) ? 1 : 0;
             HIP_TRY(launch_fir(v, fio, s));
             std::swap(g.d_state, g.d_state_alt);
             continue;
