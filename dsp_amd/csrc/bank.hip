@@ -634,8 +634,8 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     return v;
 }
 
-/* Below this many channels in a group the sequential (lane = channel) kernel
- * cannot fill 256 CUs and the time-parallel scan kernel is used instead. */
+/* From this many channels in a group the sequential (lane = channel) kernel fills the GPU; AUTO
+ * uses it there for blocks too short to give the time-parallel scan kernels a full segment. */
 constexpr size_t kAutoSeqMinChannels = 65536;
 
 int validate_design(const RTFilterDesign &d)
@@ -962,9 +962,13 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
             HIP_TRY(launch_iir_generic(v, io, s));
             continue;
         }
+        /* AUTO: the scan kernels win whenever a channel brings at least one full segment (measured,
+         * tools/seq_sweep.py: 4.5 vs 2.1 TB/s at 65 536 channels x 16K, order 8); one lane per channel
+         * wins for short blocks on wide banks (2.9 vs 0.6 TB/s at 262 144 channels x 512). */
+        const size_t short_block = g.order <= kScan2MaxOrder ? 2048 : 8192;
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
                    (bank->mode == RTFB_MODE_AUTO &&
-                    (g.chans.size() >= kAutoSeqMinChannels || !g.scan_safe));
+                    (!g.scan_safe || (g.chans.size() >= kAutoSeqMinChannels && n < short_block)));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
         else if (g.order <= kScan2MaxOrder && bank->scan_variant == 0 &&
