@@ -634,8 +634,8 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     return v;
 }
 
-/* From this many channels in a group the sequential (lane = channel) kernel fills the GPU; AUTO
- * uses it there for blocks too short to give the time-parallel scan kernels a full segment. */
+/* From this many channels in a group the sequential (lane = channel) kernel fills the GPU and AUTO
+ * uses it; below, the time-parallel scan kernels. */
 constexpr size_t kAutoSeqMinChannels = 65536;
 
 int validate_design(const RTFilterDesign &d)
@@ -962,13 +962,13 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
             HIP_TRY(launch_iir_generic(v, io, s));
             continue;
         }
-        /* AUTO: the scan kernels win whenever a channel brings at least one full segment (measured,
-         * tools/seq_sweep.py: 4.5 vs 2.1 TB/s at 65 536 channels x 16K, order 8); one lane per channel
-         * wins for short blocks on wide banks (2.9 vs 0.6 TB/s at 262 144 channels x 512). */
-        const size_t short_block = g.order <= kScan2MaxOrder ? 2048 : 8192;
+        /* AUTO: from 65 536 channels the bit-exact lane-per-channel kernel fills the GPU and streams as
+         * fast as the scan kernels (tools/seq_sweep.py, order 8: 4.3 vs 4.7 TB/s at 65 536 x 16K, 4.9 vs
+         * 3.9 TB/s at 262 144 x 4K; order 16: 3.6 vs 2.8 TB/s; short blocks: 4.5 vs 0.3 TB/s at 2^20 x 256);
+         * below that (3.3 vs 4.7 TB/s at 32 768 channels) the time-parallel kernels win. */
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
                    (bank->mode == RTFB_MODE_AUTO &&
-                    (!g.scan_safe || (g.chans.size() >= kAutoSeqMinChannels && n < short_block)));
+                    (!g.scan_safe || g.chans.size() >= kAutoSeqMinChannels));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
         else if (g.order <= kScan2MaxOrder && bank->scan_variant == 0 &&

@@ -79,8 +79,55 @@ iir_seq_kernel(GroupView g, BlockIO io)
     int ini = g.init[gc];
 
     const size_t n = io.n;
+
+    /* Full tiles (64 live channels, T samples, 16-byte aligned rows): unconditional 16-byte loads,
+     * and the next tile's loads are issued before the current one is filtered -- a guarded load
+     * becomes a branch and then every load of the lane waits for the one before it. */
+    const bool wide = g0 + kWave <= g.count && io.aligned16;
+    const int st_r = lane / TG::kPiecesPerRow;          /* piece i*64+lane: row i*(64/ppr) + st_r, column st_q */
+    const int st_q = lane % TG::kPiecesPerRow;
+    constexpr int kRowsPerPass = kWave / TG::kPiecesPerRow;
+    d2 pre[TG::kLoads];
+    auto fetch = [&](size_t t0) {
+#pragma unroll
+        for (int i = 0; i < TG::kLoads; ++i) {
+            const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
+            pre[i] = *reinterpret_cast<const d2 *>(io.in + (size_t)cr * io.ld_in + t0 + 2 * st_q);
+        }
+    };
+    if (wide && n >= (size_t)T) fetch(0);
+
     for (size_t t0 = 0; t0 < n; t0 += T) {
         const int cnt = (n - t0 < (size_t)T) ? (int)(n - t0) : T;
+
+        if (wide && cnt == T) {
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i)
+                *reinterpret_cast<d2 *>(smem + (i * kRowsPerPass + st_r) * TG::kRowBytes + st_q * 16) = pre[i];
+            wave_sync();
+            if (t0 + 2 * T <= n) fetch(t0 + T);
+
+            char *row = smem + lane * TG::kRowBytes;
+#pragma unroll 2
+            for (int k = 0; k < T; k += 2) {
+                d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
+                if (ini != 0) { y = iir_seed_ref<N>(xv.x, s, b, a); ini = 0; }
+                else y = iir_step_ref<N, kUnitA0>(xv.x, s, b, a);
+                xv.x = y;
+                y = iir_step_ref<N, kUnitA0>(xv.y, s, b, a);
+                xv.y = y;
+                *reinterpret_cast<d2 *>(row + k * 8) = xv;
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
+                *reinterpret_cast<d2 *>(io.out + (size_t)cr * io.ld_out + t0 + 2 * st_q) =
+                    *reinterpret_cast<const d2 *>(smem + (i * kRowsPerPass + st_r) * TG::kRowBytes + st_q * 16);
+            }
+            wave_sync();
+            continue;
+        }
 
         /* stage in: piece p = i*64+lane -> row p/(T/2), 16-byte column p%(T/2) */
 #pragma unroll 4

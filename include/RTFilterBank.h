@@ -54,10 +54,10 @@ typedef struct RTFilterDesign {
 
 /* Kernel choice.
  * AUTO        fastest kernels that meet the 1e-12 relative-to-peak bar: IIR channels on the
- *             time-parallel scan kernels when the design passes the conditioning probe (else bit-exact
- *             sequential; also sequential for blocks shorter than one scan segment on banks of
- *             >= 65536 channels, where one lane per channel is faster); FIR channels of >= 12 taps on
- *             the Toeplitz-tile FP64 MFMA kernel (else bit-exact).
+ *             time-parallel scan kernels when their group has fewer than 65536 channels (too few to
+ *             fill the GPU with one lane per channel) and the design passes the conditioning probe,
+ *             else on the bit-exact sequential kernel; FIR channels of >= 12 taps on the
+ *             Toeplitz-tile FP64 MFMA kernel (else bit-exact).
  * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
  * SCAN        like AUTO but IIR channels always on the scan kernel (no probe, caller's choice). */
 #define RTFB_MODE_AUTO        0
