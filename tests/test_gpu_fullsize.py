@@ -1,0 +1,166 @@
+"""Parity at BASELINE.json's full sizes, where the oracle cannot follow sample by sample: size-independent
+properties of the path (block-split invariance, agreement of the re-associated kernels with the bit-exact
+kernels -- which the small tests pin to the reference bit for bit --, linearity) plus spot checks of whole
+channels against the oracle.  Tolerance 1e-12 relative to each channel's output peak (north star)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _rel_to_peak_dev(y, yref):
+    """per-row max|y - yref| / max|yref| on the device"""
+    peak = yref.abs().amax(dim=1).clamp_min(1e-300)
+    return ((y - yref).abs().amax(dim=1) / peak).max().item()
+
+
+def test_config2_full_size_scan_vs_bit_exact_kernel_and_oracle_spot_checks(G):
+    """1024-channel order-8 bank, 2^20 samples per channel streamed in 64K blocks (config 2)."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    _, b, a = util.design_coefs("bw4_bp_0.3_0.6")
+    C_, L, B = 1024, 1 << 20, 1 << 16
+    pitch = L + 128
+    xb = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+    x = xb[:, :L]
+    gbank.synth_fill(x, 0x5EED0002)
+    ys = {}
+    for name, mode in (("scan", gbank.MODE_AUTO), ("seq", gbank.MODE_SEQUENTIAL)):
+        bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * C_, mode=mode)
+        y = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+        for j in range(L // B):
+            bank.updaten_ptr(y.data_ptr() + j * B * 8, pitch, x.data_ptr() + j * B * 8, pitch, B)
+        torch.cuda.synchronize()
+        ys[name] = (y[:, :L], bank.get_state())
+        bank.close()
+    # the re-associated kernel agrees with the bit-exact one on every channel over the whole stream
+    assert _rel_to_peak_dev(ys["scan"][0], ys["seq"][0]) <= TOL
+    st_s, st_q = ys["scan"][1][0], ys["seq"][1][0]
+    assert np.max(np.abs(st_s - st_q)) <= TOL * max(1.0, np.max(np.abs(st_q)))
+    # whole channels against the oracle: the sequential kernel to the bit, the scan kernel to 1e-12
+    for c in (0, 511, 1023):
+        want = orc.iir(b, a).updaten(util.synth(0x5EED0002, c, 0, L))
+        assert util.bits_equal(ys["seq"][0][c].cpu().numpy(), want)
+        got = ys["scan"][0][c].cpu().numpy()
+        assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    # block-split invariance: one 2^20 call == sixteen 64K calls
+    bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * C_)
+    y1 = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+    bank.updaten_ptr(y1.data_ptr(), pitch, x.data_ptr(), pitch, L)
+    torch.cuda.synchronize()
+    assert _rel_to_peak_dev(y1[:, :L], ys["scan"][0]) <= TOL
+    bank.close()
+
+
+def test_config2_linearity_at_full_block(G):
+    """filter(4 x1 + x2) == 4 filter(x1) + filter(x2) for streams already running (no stable_init in the way)."""
+    import torch
+    from dsp_amd import bank as gbank
+    _, b, a = util.design_coefs("bw4_bp_0.3_0.6")
+    C_, B = 1024, 1 << 16
+    x1 = torch.empty((C_, B), dtype=torch.float64, device="cuda")
+    x2 = torch.empty((C_, B), dtype=torch.float64, device="cuda")
+    gbank.synth_fill(x1, 1)
+    gbank.synth_fill(x2, 2)
+    outs = []
+    for x in (x1, x2, 4.0 * x1 + x2):
+        bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * C_)
+        st, fv, ini = bank.get_state()
+        bank.set_state(st, fv, np.zeros_like(ini))          # initialised, zero state
+        outs.append(bank(x))
+        bank.close()
+    torch.cuda.synchronize()
+    assert _rel_to_peak_dev(outs[2], 4.0 * outs[0] + outs[1]) <= 4 * TOL
+
+
+def test_config3_block_mfma_vs_bit_exact_kernel_and_oracle_spot_checks(G):
+    """512-tap FIR, 64K-sample blocks (config 3 with 4096 of its 65 536 channels), two consecutive blocks."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    _, b, _ = util.design_coefs("fir512_lp_0.25")
+    C_, B = 4096, 1 << 16
+    x = torch.empty((C_, 2 * B), dtype=torch.float64, device="cuda")
+    gbank.synth_fill(x, 0x5EED0002)
+    res = {}
+    for name, mode in (("mfma", gbank.MODE_AUTO), ("exact", gbank.MODE_SEQUENTIAL)):
+        bank = gbank.FilterBank([gbank.fir_design(b)], [0] * C_, mode=mode)
+        y = torch.empty_like(x)
+        for j in range(2):
+            bank.updaten_ptr(y.data_ptr() + j * B * 8, 2 * B, x.data_ptr() + j * B * 8, 2 * B, B)
+        torch.cuda.synchronize()
+        res[name] = (y, bank.get_state())
+        bank.close()
+    assert _rel_to_peak_dev(res["mfma"][0], res["exact"][0]) <= TOL
+    assert util.bits_equal(res["mfma"][1][0], res["exact"][1][0])      # the carried delay line: exact in both modes
+    for c in (0, 4095):
+        want = orc.fir(b).updaten(util.synth(0x5EED0002, c, 0, 2 * B))
+        assert util.bits_equal(res["exact"][0][c].cpu().numpy(), want)
+        got = res["mfma"][0][c].cpu().numpy()
+        assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+
+
+def test_config4_wide_mixed_bank_auto_vs_bit_exact(G):
+    """262 144 channels, four interleaved designs (IIR 8 / IIR 16 / FIR 32 / IIR 5), 4096-sample blocks:
+    every group gathers its channels through a list; the IIR groups have 65 536 channels (lane-per-channel
+    kernel in AUTO as well), the FIR group runs on the matrix cores in AUTO."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    keys = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "fir32_lp_0.25", "bw5_lp_0.25"]
+    designs = [G.golden_design(k) for k in keys]
+    C_, B = 1 << 18, 4096
+    idx = [c % 4 for c in range(C_)]
+    x = torch.empty((C_, 2 * B), dtype=torch.float64, device="cuda")
+    gbank.synth_fill(x, 44)
+    res = {}
+    for name, mode in (("auto", gbank.MODE_AUTO), ("exact", gbank.MODE_SEQUENTIAL)):
+        bank = gbank.FilterBank(designs, idx, mode=mode)
+        y = torch.empty_like(x)
+        for j in range(2):
+            bank.updaten_ptr(y.data_ptr() + j * B * 8, 2 * B, x.data_ptr() + j * B * 8, 2 * B, B)
+        torch.cuda.synchronize()
+        res[name] = y
+        bank.close()
+    assert _rel_to_peak_dev(res["auto"], res["exact"]) <= TOL
+    for c in (0, 1, 2, 3, C_ - 4, C_ - 3, C_ - 2, C_ - 1):
+        d = G.to_orc_design(designs[c % 4])
+        f = orc.Filter(d["kind"], d["b"], d.get("a"), d["init_mode"])
+        want = f.updaten(util.synth(44, c, 0, 2 * B))
+        assert util.bits_equal(res["exact"][c].cpu().numpy(), want), c
+
+
+def test_config5_long_stream_vs_oracle(G):
+    """One 2^26-sample stream through the 16th-order filter of config 5, split in time on the GPU."""
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    _, b, a = util.design_coefs("bw8_bp_0.25_0.75")
+    n = 1 << 26
+    x = torch.empty((1, n), dtype=torch.float64, device="cuda")
+    gbank.synth_fill(x, 0x5EED0002)
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    y = fs(x.view(-1))
+    torch.cuda.synchronize()
+    assert fs.last_split >= 1024
+    ref = orc.iir(b, a)
+    want = ref.updaten(util.synth(0x5EED0002, 0, 0, n))
+    got = y.cpu().numpy()
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    st, fv, ini = fs.get_state()
+    assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+    fs.close()
