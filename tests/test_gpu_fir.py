@@ -161,3 +161,29 @@ def test_fir_from_filters_sync_to_host(G, exact):
     assert util.bits_equal(np.array(f_stable.state()), o0.state)
     assert util.bits_equal(np.array(f_ramp.state()), o1.state)
     assert f_ramp.initialized == 0
+
+
+@pytest.mark.parametrize("K", [700, 4096])
+def test_fir_very_long_filters_both_modes(G, K):
+    """Up to kMaxFirTaps = 4096: the matrix-core kernel prefetches 19 inputs per thread (K <= 753) and loads the
+    rest at staging time; LDS beyond 64 KB per workgroup."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    b = np.random.default_rng(K).standard_normal(K) / K
+    for mode in (gbank.MODE_SEQUENTIAL, gbank.MODE_AUTO):
+        bank = gbank.FilterBank([gbank.fir_design(b)], [0, 0, 0], mode=mode)
+        ref = [orc.fir(b) for _ in range(3)]
+        pos = 0
+        for n in (10000, 3000, 20000):
+            x = np.stack([util.synth(5, c, pos, n) for c in range(3)])
+            y = bank(torch.from_numpy(x).cuda()).cpu().numpy()
+            want = np.stack([ref[c].updaten(x[c]) for c in range(3)])
+            if mode == gbank.MODE_SEQUENTIAL:
+                assert util.bits_equal(y, want)
+            else:
+                assert np.all(util.rel_to_peak(y, want) <= TOL_MFMA)
+            pos += n
+        st = bank.get_state()[0]
+        assert util.bits_equal(st[:, :K], np.stack([r.state for r in ref]))
+        bank.close()
