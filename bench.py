@@ -89,8 +89,9 @@ def main():
                     help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3; "
                          "stream16 = config 5 (one 2^30-sample stream, 16th-order IIR, split in time)")
     ap.add_argument("--stream-log2", type=int, default=30)
-    ap.add_argument("--mixed-channels", type=int, default=131072,
-                    help="config 4: channels per GPU (2^20 over 8 GPUs)")
+    ap.add_argument("--mixed-channels", type=int, default=65536,
+                    help="config 4: channels per wave (SURVEY.md 8(d): 2^16)")
+    ap.add_argument("--mixed-layout", choices=["sorted", "interleaved"], default="sorted")
     ap.add_argument("--gather", action="store_true",
                     help="config 4: all_gather every channel's filtered_value after each block (RCCL)")
     ap.add_argument("--fir-channels", type=int, default=65536)
@@ -300,15 +301,17 @@ def main_fir512(args):
 
 
 def main_mixed(args):
-    """BASELINE.json config 4: 2^20-channel mixed FIR/IIR bank x 64K samples, channel-sharded: every GPU
-    owns 131 072 channels (2^20 at 8 GPUs => WEAK scaling), interleaved designs
-      c % 4 == 0: IIR order 8 (butterworth(4,0.3,0.6))      c % 4 == 1: IIR order 16 (butterworth(8,0.25,0.75))
-      c % 4 == 2: FIR 32 taps (windowed sinc 0.25)          c % 4 == 3: IIR order 5 (butterworth(5, lp 0.25))
-    so every kernel group addresses its channels through a gather list.  One STEP = one
-    RTFilterBank_updaten over the 64K-sample block of all the rank's channels (64 GiB read + 64 GiB
-    written); consecutive steps continue the streams.  With --gather the ranks all_gather the
-    filtered_value of every channel after each block (the real-time consumer's view; 8 MiB at 2^20
-    channels) -- the sample blocks themselves stay sharded (they would not fit one GPU)."""
+    """BASELINE.json config 4 as SURVEY.md 8(d) pins it: a 2^20-channel bank, channels sorted by type -- the
+    first 2^19 are the 8th-order IIR of config 2, the next 2^19 a 32-tap windowed-sinc FIR -- x 65 536 samples,
+    contiguous channel ranges of 2^20/N per GPU, processed in WAVES of 2^16 channels (32 GiB in + 32 GiB out:
+    the whole bank does not fit below 8 GPUs, and the same wave size at every GPU count keeps numbers comparable).
+    One STEP = one RTFilterBank_updaten over one wave; steps walk the rank's waves, alternating types where the
+    rank owns both (N = 1, 2), so that `value` averages over the bank's mix.  Every wave has its own bank (its own
+    carried state); the sample buffer is shared between waves (its content does not affect the timing).
+    `--mixed-layout interleaved` is the harder variant: four designs (IIR 8 / IIR 16 / FIR 32 / IIR 5) interleaved
+    channel by channel, so that every kernel group gathers its channels through a list.
+    With --gather the ranks all_gather the filtered_value of the wave's channels after each step (the real-time
+    consumer's view); the sample blocks themselves stay sharded."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -320,24 +323,44 @@ def main_mixed(args):
     dev = torch.device("cuda", local)
     from dsp_amd import bank as gbank
     from tests import util
-    nch = args.mixed_channels
-    keys = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "fir32_lp_0.25", "bw5_lp_0.25"]
-    designs = []
-    for k in keys:
-        kind, b, a = util.design_coefs(k)
-        designs.append(gbank.fir_design(b) if k.startswith("fir") else gbank.iir_design(b, a))
     mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_SCAN, seq=gbank.MODE_SEQUENTIAL)[args.mode]
-    bank = gbank.FilterBank(designs, [(rank * nch + c) % 4 for c in range(nch)], device=local, mode=mode)
+
+    def design(key):
+        kind, b, a = util.design_coefs(key)
+        return gbank.fir_design(b) if kind != "iir" else gbank.iir_design(b, a)
+
+    wave = args.mixed_channels                       # channels per wave (2^16)
+    total = 1 << 20
+    per_rank = total // world
+    nwaves = max(1, per_rank // wave)
+    banks, kinds = [], []
+    if args.mixed_layout == "sorted":
+        for w in range(nwaves):
+            g0 = rank * per_rank + w * wave
+            key = "bw4_bp_0.3_0.6" if g0 < total // 2 else "fir32_lp_0.25"
+            banks.append(gbank.FilterBank([design(key)], [0] * wave, device=local, mode=mode))
+            kinds.append("iir8" if g0 < total // 2 else "fir32")
+        order = sorted(range(nwaves), key=lambda w: (w % (nwaves // 2 or 1), w))   # alternate the two halves
+    else:
+        keys = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "fir32_lp_0.25", "bw5_lp_0.25"]
+        for w in range(min(nwaves, 2)):
+            banks.append(gbank.FilterBank([design(k) for k in keys], [c % 4 for c in range(wave)], device=local,
+                                          mode=mode))
+            kinds.append("interleaved")
+        order = list(range(len(banks)))
     pitch = BLOCK + 128
-    xbuf = torch.empty((nch, pitch), dtype=torch.float64, device=dev)
-    ybuf = torch.empty((nch, pitch), dtype=torch.float64, device=dev)
+    xbuf = torch.empty((wave, pitch), dtype=torch.float64, device=dev)
+    ybuf = torch.empty((wave, pitch), dtype=torch.float64, device=dev)
     x, y = xbuf[:, :BLOCK], ybuf[:, :BLOCK]
-    gbank.synth_fill(x, SEED, chan0=rank * nch, n0=0)
+    gbank.synth_fill(x, 0x5EED0004, chan0=rank * per_rank, n0=0)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
-    fv_all = torch.empty(world * nch, dtype=torch.float64, device=dev) if (dist is not None and args.gather) else None
+    fv_all = torch.empty(world * wave, dtype=torch.float64, device=dev) if (dist is not None and args.gather) else None
+    step_no = [0]
 
     def step(ev=None):
+        bank = banks[order[step_no[0] % len(order)]]
+        step_no[0] += 1
         if ev is not None:
             ev[0].record(stream)
         bank.updaten_ptr(y.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
@@ -350,6 +373,7 @@ def main_mixed(args):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(args.steps)]
+    first_timed = step_no[0]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -366,24 +390,31 @@ def main_mixed(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    step_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    step_ms = np.array([e0.elapsed_time(e1) for e0, e1 in events])
     avg_s = float(np.mean(step_ms)) / 1e3
     if rank == 0:
-        samples = nch * BLOCK
+        samples = wave * BLOCK
         achieved = samples * BYTES_PER_SAMPLE / avg_s / 1e9
+        per_kind = {}
+        for k, ms in enumerate(step_ms):
+            per_kind.setdefault(kinds[order[(first_timed + k) % len(order)]], []).append(ms)
         line = {
             "metric": "filtered Msamples/s (whole node)", "value": world * samples * args.steps / elapsed / 1e6,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 4: mixed FIR/IIR bank (IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved), "
-                                   "%d channels per GPU x 64K samples, channel-sharded" % nch,
-                       "channels_per_gpu": nch, "block": BLOCK, "row_pitch_doubles": pitch, "kernel": args.mode,
-                       "gather": bool(fv_all is not None), "parallelism": "channel-sharded x%d" % world},
+            "config": {"workload": "config 4: 2^20-channel mixed bank (%s) x 64K samples, channel-sharded, waves of %d "
+                                   "channels" % ("2^19 IIR order 8 + 2^19 FIR 32 taps, sorted by type"
+                                                 if args.mixed_layout == "sorted" else
+                                                 "IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved", wave),
+                       "channels_per_gpu": per_rank, "wave_channels": wave, "waves_per_gpu": nwaves, "block": BLOCK,
+                       "row_pitch_doubles": pitch, "kernel": args.mode, "gather": bool(fv_all is not None),
+                       "rank0_wave_ms": {k: float(np.mean(v)) for k, v in per_kind.items()},
+                       "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
-                         "note": "all kernels of one RTFilterBank_updaten (4 groups) over the call's device time",
+                         "note": "all kernels of one RTFilterBank_updaten over one wave, rank 0's device time per call",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         print(json.dumps(line), flush=True)

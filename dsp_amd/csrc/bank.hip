@@ -965,10 +965,11 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
         /* AUTO: from 65 536 channels the bit-exact lane-per-channel kernel fills the GPU and streams as
          * fast as the scan kernels (tools/seq_sweep.py, order 8: 4.3 vs 4.7 TB/s at 65 536 x 16K, 4.9 vs
          * 3.9 TB/s at 262 144 x 4K; order 16: 3.6 vs 2.8 TB/s; short blocks: 4.5 vs 0.3 TB/s at 2^20 x 256);
-         * below that (3.3 vs 4.7 TB/s at 32 768 channels) the time-parallel kernels win. */
+         * below that (3.3 vs 4.7 TB/s at 32 768 channels) the time-parallel kernels win.  Orders <= 8 switch
+         * one octave later: at exactly 65 536 channels x 64K the pipelined kernel still leads (4.6 vs 3.7 TB/s). */
+        const size_t seq_from = g.order <= kScan2MaxOrder ? 2 * kAutoSeqMinChannels : kAutoSeqMinChannels;
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
-                   (bank->mode == RTFB_MODE_AUTO &&
-                    (!g.scan_safe || g.chans.size() >= kAutoSeqMinChannels));
+                   (bank->mode == RTFB_MODE_AUTO && (!g.scan_safe || g.chans.size() >= seq_from));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
         else if (g.order <= kScan2MaxOrder && bank->scan_variant == 0 &&

@@ -115,8 +115,8 @@ def test_config3_block_mfma_vs_bit_exact_kernel_and_oracle_spot_checks(G):
 
 def test_config4_wide_mixed_bank_auto_vs_bit_exact(G):
     """262 144 channels, four interleaved designs (IIR 8 / IIR 16 / FIR 32 / IIR 5), 4096-sample blocks:
-    every group gathers its channels through a list; the IIR groups have 65 536 channels (lane-per-channel
-    kernel in AUTO as well), the FIR group runs on the matrix cores in AUTO."""
+    every group gathers its channels through a list; the IIR groups have 65 536 channels (scan kernels for
+    orders 8 and 5, lane-per-channel kernel for order 16 in AUTO), the FIR group runs on the matrix cores in AUTO."""
     import torch
     from dsp_amd import bank as gbank
     from oracle import oracle as orc
