@@ -312,7 +312,7 @@ void scan2_gtable(const Design &d, int T, std::vector<double> &out)
     for (int i = 0; i < N; ++i) out.push_back((double)acc[i]);
 }
 
-/* Row propagators of the pipelined kernel: A^(32 j), j = 0..63, row-major (long double products). */
+/* Row propagators of the pipelined kernel: A^(32 j), j = 0..63 (long double products), stored [e][j]. */
 void pipe_ttable(const Design &d, int T, std::vector<double> &out)
 {
     const int N = d.nb - 1;
@@ -332,8 +332,12 @@ void pipe_ttable(const Design &d, int T, std::vector<double> &out)
     }
     Mat AT = A;
     for (int t = 1; t < T; t <<= 1) AT = mul(AT, AT);
+    /* element-major: entry e of all 64 propagators is contiguous, so that the lanes of the back wave
+     * (lane j holds A^(32 j)) read 512 consecutive bytes per load instead of 64 separate lines */
+    const size_t base = out.size();
+    out.resize(base + (size_t)kWave * N * N);
     for (int j = 0; j < kWave; ++j) {
-        for (size_t e = 0; e < P.size(); ++e) out.push_back((double)P[e]);
+        for (size_t e = 0; e < P.size(); ++e) out[base + e * kWave + j] = (double)P[e];
         P = mul(AT, P);
     }
 }

@@ -53,7 +53,7 @@ struct GroupView {
     const int32_t *pow2_off;  /* per design: offset of the kScan2Levels matrices A^(32 2^k) */
     const int32_t *levels2;   /* per design: combine levels that still matter (decay cut)  */
     const int32_t *ttab_off;  /* per design: offset in pows of the 64 row propagators A^(32 j),
-                                 j = 0..63, row-major (pipelined kernel); -1 if not built   */
+                                 j = 0..63, stored [element][j] (pipelined kernel); -1 if not built */
     const int32_t *gtab_off;  /* per design: offset in pows of G[n][i] = (A^(31-n) B)_i, n < 32,
                                  followed by Gc[i] = (sum_m A^m e_{N-1})_i                  */
     int32_t        levels2_max;   /* largest levels2 in the group                          */
