@@ -168,6 +168,7 @@ _proto("RTFilterStream_from_design", c_int, [POINTER(c_void_p), POINTER(RTFilter
 _proto("RTFilterStream_from_filter", c_int, [POINTER(c_void_p), c_void_p, c_int])
 _proto("RTFilterStream_destroy", None, [c_void_p])
 _proto("RTFilterStream_updaten", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p])
+_proto("RTFilterStream_updaten_host", c_int, [c_void_p, _dp, _dp, c_size_t])
 _proto("RTFilterStream_reset", c_int, [c_void_p, c_void_p])
 _proto("RTFilterStream_sync_to_host", c_int, [c_void_p, c_void_p])
 _proto("RTFilterStream_decay_length", c_size_t, [c_void_p])

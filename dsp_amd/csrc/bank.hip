@@ -1138,6 +1138,10 @@ struct RTFilterStream {
     std::map<size_t, SplitBanks> split;       /* by C */
     double *d_scratch = nullptr;              /* outputs of the run-ups (discarded) */
     size_t scratch_doubles = 0;
+    /* RTFilterStream_updaten_host: two device chunk pairs and three streams, created on first use */
+    double *d_hin[2] = {nullptr, nullptr}, *d_hout[2] = {nullptr, nullptr};
+    hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -1323,6 +1327,19 @@ void RTFilterStream_destroy(RTFilterStream *st)
     RTFilterBank_destroy(st->tail);
     RTFilterBank_destroy(st->one);             /* synchronises the device */
     pool_free(st->d_scratch);
+    {
+        DeviceScope ds(st->device);
+        for (int k = 0; k < 2; ++k) {
+            pool_free(st->d_hin[k]);
+            pool_free(st->d_hout[k]);
+            if (st->ev_in[k]) (void)hipEventDestroy(st->ev_in[k]);
+            if (st->ev_run[k]) (void)hipEventDestroy(st->ev_run[k]);
+            if (st->ev_out[k]) (void)hipEventDestroy(st->ev_out[k]);
+        }
+        if (st->hs_in) (void)hipStreamDestroy(st->hs_in);
+        if (st->hs_run) (void)hipStreamDestroy(st->hs_run);
+        if (st->hs_out) (void)hipStreamDestroy(st->hs_out);
+    }
     delete st;
 }
 
@@ -1359,6 +1376,53 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         in += C * Lc;
         n -= C * Lc;
     }
+    return RTFB_OK;
+}
+
+int RTFilterStream_updaten_host(RTFilterStream *st, double *out, const double *in, size_t n)
+{
+    if (!st || !out || !in) return fail(RTFB_EINVAL, "RTFilterStream_updaten_host: NULL argument");
+    if (!n) return RTFB_OK;
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    constexpr size_t kChunk = (size_t)1 << 23;             /* 64 MiB each way */
+    if (!st->hs_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&st->hs_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&st->hs_run, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&st->hs_out, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&st->ev_in[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&st->ev_run[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&st->ev_out[k], hipEventDisableTiming));
+            void *p = nullptr;
+            int rc = pool_alloc(&p, kChunk * sizeof(double), st->device);
+            if (rc) return rc;
+            st->d_hin[k] = static_cast<double *>(p);
+            rc = pool_alloc(&p, kChunk * sizeof(double), st->device);
+            if (rc) return rc;
+            st->d_hout[k] = static_cast<double *>(p);
+        }
+    }
+    /* chunk k: copy in on hs_in (after chunk k-2 left its input buffer), filter on hs_run (in order:
+     * the state carries), copy out on hs_out (the output buffer is reused after chunk k-2 went out) */
+    size_t k = 0;
+    for (size_t pos = 0; pos < n; pos += kChunk, ++k) {
+        const size_t len = std::min(kChunk, n - pos);
+        const int slot = (int)(k & 1);
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(st->hs_in, st->ev_run[slot], 0));
+        HIP_TRY(hipMemcpyAsync(st->d_hin[slot], in + pos, len * sizeof(double), hipMemcpyHostToDevice, st->hs_in));
+        HIP_TRY(hipEventRecord(st->ev_in[slot], st->hs_in));
+        HIP_TRY(hipStreamWaitEvent(st->hs_run, st->ev_in[slot], 0));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(st->hs_run, st->ev_out[slot], 0));
+        int rc = RTFilterStream_updaten(st, st->d_hout[slot], st->d_hin[slot], len, st->hs_run);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(st->ev_run[slot], st->hs_run));
+        HIP_TRY(hipStreamWaitEvent(st->hs_out, st->ev_run[slot], 0));
+        HIP_TRY(hipMemcpyAsync(out + pos, st->d_hout[slot], len * sizeof(double), hipMemcpyDeviceToHost, st->hs_out));
+        HIP_TRY(hipEventRecord(st->ev_out[slot], st->hs_out));
+    }
+    HIP_TRY(hipStreamSynchronize(st->hs_out));
+    HIP_TRY(hipStreamSynchronize(st->hs_run));
     return RTFB_OK;
 }
 

@@ -62,6 +62,17 @@ class FilterStream:
         self.updaten_ptr(out.data_ptr(), x.data_ptr(), x.numel(), stream)
         return out
 
+    def filter_host(self, x, out=None):
+        """x: 1-D float64 numpy array in host memory; the reference call on host buffers, moved through the
+        GPU in double-buffered chunks (bounded by the host link).  Returns `out` (a new array by default)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if out is None:
+            out = np.empty_like(x)
+        _check(dspdll.RTFilterStream_updaten_host(self._h, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  x.ctypes.data_as(C.POINTER(C.c_double)), x.size),
+               "RTFilterStream_updaten_host")
+        return out
+
     def reset(self, stream=None):
         _check(dspdll.RTFilterStream_reset(self._h, _stream_ptr(stream)), "RTFilterStream_reset")
 

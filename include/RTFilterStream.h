@@ -49,6 +49,12 @@ EXPORT void RTFilterStream_destroy(RTFilterStream *stream);
  * `hip_stream` (a hipStream_t, NULL = default) and returns.  State carries to the next call. */
 EXPORT int RTFilterStream_updaten(RTFilterStream *stream, double *out, const double *in, size_t n,
                                   void *hip_stream);
+/* The same for HOST buffers, i.e. the reference call as an unchanged caller makes it:
+ * in/out are ordinary (pageable) host arrays of n doubles, in == out allowed.  The stream is moved through
+ * the GPU in chunks of 2^23 samples, double-buffered (copy-in of chunk k+1 and copy-out of chunk k-1 overlap
+ * the filtering of chunk k); throughput is bounded by the host link (PCIe: ~16 B/sample at a few tens of GB/s),
+ * never by the kernels.  Blocks until out[] is complete. */
+EXPORT int RTFilterStream_updaten_host(RTFilterStream *stream, double *out, const double *in, size_t n);
 /* RTFilter_reset (src/RTFilter.c:55-58): initialized = FILTER_RESET, state untouched. */
 EXPORT int RTFilterStream_reset(RTFilterStream *stream, void *hip_stream);
 /* Host structs given to _from_filter take state, filtered_value, initialized.  Synchronises. */

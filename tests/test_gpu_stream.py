@@ -215,3 +215,30 @@ def test_two_ranks_on_one_gpu_split_the_stream(G):
     want = ref.updaten(util.synth(21, 0, 0, 2 * n))
     assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
     assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+
+
+def test_host_buffers_through_the_gpu(G):
+    """RTFilterStream_updaten_host: pageable host arrays, several chunks, state carried across calls, in place."""
+    import time
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _designs()["bw8"]
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    ref = orc.iir(b, a)
+    pos = 0
+    for n in ((1 << 24) + 12345, 1000, (1 << 23) * 3):
+        x = util.synth(31, 0, pos, n)
+        t0 = time.perf_counter()
+        y = fs.filter_host(x)
+        dt = time.perf_counter() - t0
+        want = ref.updaten(x)
+        assert np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+        if n > (1 << 24):
+            print("host round trip: %.0f Msamples/s (%.1f GB/s each way)" % (n / dt / 1e6, n * 8 / dt / 1e9))
+        pos += n
+    x = util.synth(31, 0, pos, 1 << 22)
+    want = ref.updaten(x)
+    fs.filter_host(x, out=x)
+    assert np.max(np.abs(x - want)) <= TOL * np.max(np.abs(want))
+    fs.close()
