@@ -61,9 +61,30 @@ def cpu_baseline(b, a):
         list(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
     nsamp = threads * per_thread * STREAM
+    # SURVEY.md 8(d) column (a): one thread, one channel, 2^22 samples, median of 5 after a warm-up
+    x1 = util.synth(SEED, 0, 0, 1 << 22)
+    one = []
+    for rep in range(6):
+        f = ref.RefIIR(b, a) if kind == "reference" else orc.iir(b, a)
+        t1 = time.perf_counter()
+        f.updaten(x1)
+        one.append(time.perf_counter() - t1)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return dict(value=nsamp / dt / 1e6, unit="Msamples/s", cores=threads, kind=kind,
+                single_thread_value=(1 << 22) / float(np.median(one[1:])) / 1e6,
+                cpu_model=model, host_cpus_visible=os.cpu_count(),
                 sample="%d channels x 2^20 samples of config 2 (%s), RTFilter_updaten per channel, "
-                       "%d host threads, %.1f s" % (threads * per_thread, DESIGN, threads, dt))
+                       "%d host threads (one channel range each, SMT siblings not distinguished), %.1f s; "
+                       "single_thread_value: one channel, 2^22 samples, median of 5"
+                       % (threads * per_thread, DESIGN, threads, dt))
 
 
 def measured_traffic(name="r1_traffic.json"):
