@@ -185,22 +185,26 @@ fir_main_kernel(GroupView g, BlockIO io, int seg0)
     }
 }
 
-/* Steady-state segments, bit-exact, one output per lane at a time.
- * A workgroup (4 waves) takes S = 2048 consecutive outputs of one channel; thread t owns outputs
- * t, t+256, ..., t+7*256 of the segment.  For every tap k = K-1 .. 1 (oldest input first, the
- * reference's order) the tap is a wave-uniform scalar and the eight inputs x[m-k] come from LDS at
- * consecutive addresses across lanes (conflict-free, immediate offsets): K LDS reads and 2K VALU
- * operations per output, eight independent accumulation chains per lane, results stored straight
- * from the registers, coalesced.  No skew, no per-lane tap windows: this replaced a lane = 32
- * outputs tiling that ran at 2.0 TB/s for 2 taps and 1.2 TB/s for 32. */
+/* Steady-state segments, bit-exact.
+ * A workgroup (4 waves) takes S = 2048 consecutive outputs of one channel; thread t owns the output PAIRS
+ * (2t, 2t+1) + 512 j, j = 0..3.  Taps go oldest input first (the reference's order), two per step:
+ *     tap k   (k even):  acc0 += b[k] x[m0-k],      acc1 += b[k] x[m0-k+1]
+ *     tap k-1:           acc0 += b[k-1] x[m0-k+1],  acc1 += b[k-1] x[m0-k+2]
+ * so a step needs the aligned input pair it already holds plus the next aligned pair: ONE 16-byte LDS read
+ * (consecutive across lanes: conflict-free) per two taps and two outputs, against four 8-byte reads for
+ * one output per lane.  Taps are wave-uniform scalars, every product and sum is rounded separately, eight
+ * independent accumulation chains per lane, results stored straight from the registers (16 B per lane).
+ * The staged inputs start on an even LDS index when K-1-k is even for even k, i.e. they are shifted by
+ * one slot when K is even.  History: lane = 32 outputs tiling 2.0 / 1.2 / 0.5 TB/s at 2 / 32 / 128 taps;
+ * one output per lane 4.9 / 3.1 / 1.0; this kernel: see tools/fir_sweep.py. */
 constexpr int kDirThreads = 256;
-constexpr int kDirPer = S / kDirThreads;             /* 8 outputs per thread */
+constexpr int kDirPairs = S / (2 * kDirThreads);     /* 4 output pairs per thread */
 
 __global__ void __launch_bounds__(kDirThreads)
 fir_direct_kernel(GroupView g, BlockIO io, int seg0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *xs = reinterpret_cast<double *>(smem_raw);
+    double *lds = reinterpret_cast<double *>(smem_raw);
 
     const int tid = threadIdx.x;
     const int gi = blockIdx.y;
@@ -215,33 +219,66 @@ fir_direct_kernel(GroupView g, BlockIO io, int seg0)
     double *out = io.out + (size_t)chan * io.ld_out + seg_base;
     const double tail = as_const(g.state + (size_t)gi * g.state_ld)[K - 1];   /* written by earlier kernels only */
 
-    /* stage x[seg_base-(K-1) .. seg_base+S); past the end of the block: the last sample again (only
-     * outputs that are not stored ever see it) -- unconditional loads, all in flight together */
+    /* stage x[seg_base-(K-1) .. seg_base+S) at LDS index pad + e; past the end of the block: the last sample
+     * again (only outputs that are not stored ever see it) -- unconditional loads, all in flight together */
+    const int pad = (K - 1) & 1;
+    double *xs = lds + pad;
     const int total = S + K - 1;
     const long long last = n - 1 - (seg_base - (K - 1));
     const int emax = last < total - 1 ? (int)last : total - 1;
     for (int e = tid; e < total; e += kDirThreads) xs[e] = x[e < emax ? e : emax];
     lds_barrier();
 
-    double acc[kDirPer];
+    double acc0[kDirPairs], acc1[kDirPairs];
 #pragma unroll
-    for (int j = 0; j < kDirPer; ++j) acc[j] = tail;
-    const double *xp = xs + (K - 1) + tid;                    /* xp[256 j - k] = x[m_j - k] */
-#pragma unroll 4
-    for (int k = K - 1; k >= 1; --k) {
+    for (int j = 0; j < kDirPairs; ++j) acc0[j] = acc1[j] = tail;
+    const double *xp = xs + (K - 1) + 2 * tid;                /* xp[512 j - k] = x[m0_j - k] */
+    int k = K - 1;
+    if (k & 1) {                                              /* odd leading tap on its own */
         const double bk = b[k];
 #pragma unroll
-        for (int j = 0; j < kDirPer; ++j) {
-            const double p = bk * xp[kDirThreads * j - k];
-            acc[j] = acc[j] + p;
+        for (int j = 0; j < kDirPairs; ++j) {
+            const double p0 = bk * xp[2 * kDirThreads * j - k];
+            const double p1 = bk * xp[2 * kDirThreads * j - k + 1];
+            acc0[j] = acc0[j] + p0;
+            acc1[j] = acc1[j] + p1;
+        }
+        --k;
+    }
+    /* k even: xp[.. - k] is 16-byte aligned */
+    d2 cur[kDirPairs];
+#pragma unroll
+    for (int j = 0; j < kDirPairs; ++j) cur[j] = *reinterpret_cast<const d2 *>(xp + 2 * kDirThreads * j - k);
+#pragma unroll 2
+    for (; k >= 2; k -= 2) {
+        const double bk = b[k], bk1 = b[k - 1];
+#pragma unroll
+        for (int j = 0; j < kDirPairs; ++j) {
+            const d2 nxt = *reinterpret_cast<const d2 *>(xp + 2 * kDirThreads * j - k + 2);
+            const double p0 = bk * cur[j].x, p1 = bk * cur[j].y;
+            acc0[j] = acc0[j] + p0;
+            acc1[j] = acc1[j] + p1;
+            const double q0 = bk1 * cur[j].y, q1 = bk1 * nxt.x;
+            acc0[j] = acc0[j] + q0;
+            acc1[j] = acc1[j] + q1;
+            cur[j] = nxt;
         }
     }
+    /* k == 0: cur = (x[m0], x[m0+1]) */
     const double b0 = b[0];
+    const bool vec = io.aligned16;
 #pragma unroll
-    for (int j = 0; j < kDirPer; ++j) {
-        double v = xp[kDirThreads * j] * b0;
-        v = v + acc[j];
-        if (seg_base + tid + kDirThreads * j < n) out[tid + kDirThreads * j] = v;
+    for (int j = 0; j < kDirPairs; ++j) {
+        double v0 = cur[j].x * b0, v1 = cur[j].y * b0;
+        v0 = v0 + acc0[j];
+        v1 = v1 + acc1[j];
+        const int o = 2 * tid + 2 * kDirThreads * j;
+        if (vec && seg_base + o + 1 < n) {
+            *reinterpret_cast<d2 *>(out + o) = (d2){v0, v1};
+        } else {
+            if (seg_base + o < n) out[o] = v0;
+            if (seg_base + o + 1 < n) out[o + 1] = v1;
+        }
     }
 }
 
@@ -743,7 +780,7 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         }
         if (nseg > nhead) {
             hipLaunchKernelGGL(fir_direct_kernel, dim3(nseg - nhead, g.count), dim3(kDirThreads),
-                               (size_t)(S + g.kmax) * sizeof(double), s, g, io, nhead);
+                               (size_t)(S + g.kmax + 2) * sizeof(double), s, g, io, nhead);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
     }
