@@ -57,7 +57,7 @@ typedef struct RTFilterDesign {
  *             time-parallel scan kernels when their group has fewer than 131072 channels (65536 for
  *             orders above 8: too few to fill the GPU with one lane per channel) and the design passes
  *             the conditioning probe,
- *             else on the bit-exact sequential kernel; FIR channels of >= 12 taps on the
+ *             else on the bit-exact sequential kernel; FIR channels of >= 17 taps on the
  *             Toeplitz-tile FP64 MFMA kernel (else bit-exact).
  * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
  * SCAN        like AUTO but IIR channels always on the scan kernel (no probe, caller's choice). */
