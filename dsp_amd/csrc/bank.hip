@@ -219,6 +219,7 @@ struct Group {
     int32_t *d_aux = nullptr;           /* FIR: prologue -> main/epilogue hand-off */
     int kmax = 0;                       /* FIR: longest filter in the group        */
     bool has_partial = false;           /* FIR: a partial_init design is present    */
+    int single_design = -2;             /* design shared by all channels; -1 = several; -2 = none seen yet */
     int levels2_max = 0;                /* fast IIR: most combine levels any design needs */
     double *d_scratch = nullptr;        /* FIR, in-place calls: private copy of the input */
     size_t scratch_doubles = 0;
@@ -553,6 +554,8 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         g.levels2_max = std::max(g.levels2_max, d.levels2);
         if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
         if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
+        if (g.single_design == -2) g.single_design = bk->design_of[c];
+        else if (g.single_design != bk->design_of[c]) g.single_design = -1;
     }
 
     int rc;
@@ -619,6 +622,7 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.unit_a0 = g.unit_a0 ? 1 : 0;
     v.fir_mfma = 0;
     v.has_partial = g.has_partial ? 1 : 0;
+    v.single_design = g.single_design;
     v.fval = g.d_fval;
     v.init = g.d_init;
     v.coef_off = bk->d_coef_off;
@@ -959,7 +963,7 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
                 std::getenv("DSP_AMD_FIR_MFMA_MIN") ? std::atoi(std::getenv("DSP_AMD_FIR_MFMA_MIN")) : kFirMfmaMinTaps;
             v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= mfma_min) ? 1 : 0;
             HIP_TRY(launch_fir(v, fio, s));
-            std::swap(g.d_state, g.d_state_alt);
+            if (fir_uses_state_swap(v, fio)) std::swap(g.d_state, g.d_state_alt);
             continue;
         }
         if (g.cls == kIirGeneric) {

@@ -46,6 +46,7 @@ struct GroupView {
     int32_t        fir_mfma;  /* FIR: outputs come from the Toeplitz-tile MFMA kernel (exact head kernel
                                  only for channels inside a partial_init ramp)                  */
     int32_t        has_partial;   /* FIR: some design of the group is RTFB_KIND_FIR_PARTIAL     */
+    int32_t        single_design; /* design index shared by every channel of the group, or -1    */
     double        *fval;      /* RTFilter.filtered_value per g                            */
     int32_t       *init;      /* RTFilter.initialized per g                               */
     const int32_t *coef_off;  /* per design: offset of b[0] in coefs (a follows b)        */
@@ -83,6 +84,8 @@ hipError_t launch_iir_scan2(int order, const GroupView &g, const BlockIO &io, hi
 hipError_t launch_iir_pipe(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
+/* false when launch_fir takes the lane-per-channel kernel, which updates g.state in place (no ping-pong swap) */
+bool fir_uses_state_swap(const GroupView &g, const BlockIO &io);
 hipError_t launch_reset(const GroupView &g, hipStream_t s);
 hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t seed,
                         uint64_t chan0, uint64_t n0, hipStream_t s);

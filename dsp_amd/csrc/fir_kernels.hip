@@ -723,8 +723,211 @@ static int mfma_resident_groups(size_t lds_bytes)
     return per_cu * cus;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Short blocks on wide banks: one lane = one channel, the reference's loop itself.             */
+/*                                                                                                */
+/* The kernels above split TIME; a real-time producer hands over short blocks (tens to a few     */
+/* thousand samples) of very many channels, where a segment per workgroup leaves most lanes      */
+/* idle.  Here a wavefront owns 64 channels and walks the block in tiles of 32 samples exactly  */
+/* as RTFilter_update does (ref: src/RTFilter.c:98-108, 235-297): delay line and taps of the     */
+/* lane's channel in registers for the whole block (KP <= 32 slots, slots past the channel's own */
+/* K never touched, so s[K-1] keeps the reference's "read, never written" role), stable_init /   */
+/* partial_init inline on the samples they apply to.  Bit-exact by construction.  Tile staging   */
+/* as in iir_seq_kernel: 64 rows x 32 doubles through padded LDS, unconditional 16-byte loads    */
+/* with the next tile prefetched on full tiles.                                                  */
+
+/* kUniform: every channel of the group has the same design -- taps and K are wave-uniform scalars (SGPRs,
+ * scalar branches for the K bounds), which leaves the registers to the delay line: required for KP = 32. */
+template <int KP, bool kUniform>
+__global__ void __launch_bounds__(kWave)
+fir_seq_kernel(GroupView g, BlockIO io)
+{
+    constexpr int TT = KP > 16 ? 16 : 32;               /* 32 slots: a shorter tile keeps the prefetch in registers */
+    constexpr int kRowBytes = TT * 8 + 16;
+    constexpr int kPiecesPerRow = TT / 2, kLoads = TT / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char *smem = smem_raw;
+
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * kWave;
+    const int gi = g0 + lane;
+    const bool live = gi < g.count;
+    const int gc = live ? gi : g.count - 1;
+    const int chan = group_channel(g, gc);
+    const int dsn = kUniform ? g.single_design : g.design[gc];
+    const int K = kUniform ? as_const(g.nb)[dsn] : g.nb[dsn];
+    const bool partial = (kUniform ? as_const(g.kind)[dsn] : g.kind[dsn]) == RTFB_KIND_FIR_PARTIAL;
+
+    double b[KP], s[KP];
+    {
+        const double *st = g.state + (size_t)gc * g.state_ld;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) s[i] = i < K ? st[i] : 0.0;
+        if (kUniform) {
+            cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) b[i] = i < K ? cf[i] : 0.0;
+        } else {
+            const double *cf = g.coefs + g.coef_off[dsn];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) b[i] = i < K ? cf[i] : 0.0;
+        }
+    }
+    double y = g.fval[gc];
+    int ini = g.init[gc];
+    const double kd = (double)(size_t)K;
+
+    auto one_sample = [&](double x) {
+        if (ini == 0) {                                      /* RTFIRFilter_update, ref :235-247 */
+            double v = x * b[0];
+            y = v + s[0];
+        } else if (!partial) {                               /* RTFIRFilter_stable_init, ref :250-265 */
+            double run = 0.0;
+#pragma unroll
+            for (int i = KP - 1; i >= 1; --i) {
+                s[i] = (i == K - 1) ? 0.0 : s[i];            /* a select: `if (i == K-1) s[i] = 0` folds into a
+                                                                dynamically indexed store and sends s[] to scratch */
+                if (i <= K - 1) {
+                    run = run + b[i];
+                    s[i - 1] = run * x;
+                }
+            }
+            s[0] = (K == 1) ? 0.0 : s[0];
+            y = x;
+            ini = 0;
+            return;                                          /* no delay-line update on this sample */
+        } else if (ini == FILTER_RESET) {                    /* RTFIRFilter_partial_init, ref :279-282 */
+#pragma unroll
+            for (int i = 0; i < KP; ++i) s[i] = (i == K - 1) ? 0.0 : s[i];
+            y = x;
+            ini = K - 1;
+        } else {                                             /* ... :283-286 */
+            ini -= 1;
+            double v = x * b[0];
+            v = v + s[0];
+            v = kd * v;
+            y = v / (double)(size_t)(K - ini);
+        }
+#pragma unroll
+        for (int i = 0; i < KP - 1; ++i) {                   /* :242-245 / :287-291 */
+            if (i < K - 1) {
+                const double p = b[i + 1] * x;
+                s[i] = s[i + 1] + p;
+            }
+        }
+    };
+
+    const size_t n = io.n;
+    const bool wide = g0 + kWave <= g.count && io.aligned16;
+    const int st_r = lane / kPiecesPerRow, st_q = lane % kPiecesPerRow;
+    constexpr int kRowsPerPass = kWave / kPiecesPerRow;
+    d2 pre[kLoads];
+    auto fetch = [&](size_t t0) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
+            pre[i] = *reinterpret_cast<const d2 *>(io.in + (size_t)cr * io.ld_in + t0 + 2 * st_q);
+        }
+    };
+    if (wide && n >= (size_t)TT) fetch(0);
+
+    for (size_t t0 = 0; t0 < n; t0 += TT) {
+        const int cnt = (n - t0 < (size_t)TT) ? (int)(n - t0) : TT;
+        char *row = smem + lane * kRowBytes;
+        if (wide && cnt == TT) {
+#pragma unroll
+            for (int i = 0; i < kLoads; ++i)
+                *reinterpret_cast<d2 *>(smem + (i * kRowsPerPass + st_r) * kRowBytes + st_q * 16) = pre[i];
+            wave_sync();
+            if (t0 + 2 * TT <= n) fetch(t0 + TT);
+#pragma unroll 1
+            for (int k = 0; k < TT; k += 2) {
+                d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
+                one_sample(xv.x);
+                xv.x = y;
+                one_sample(xv.y);
+                xv.y = y;
+                *reinterpret_cast<d2 *>(row + k * 8) = xv;
+            }
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < kLoads; ++i) {
+                const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
+                *reinterpret_cast<d2 *>(io.out + (size_t)cr * io.ld_out + t0 + 2 * st_q) =
+                    *reinterpret_cast<const d2 *>(smem + (i * kRowsPerPass + st_r) * kRowBytes + st_q * 16);
+            }
+            wave_sync();
+            continue;
+        }
+        /* ragged tile: element-wise, guarded */
+        for (int i = 0; i < kLoads * 2; ++i) {
+            const int p = i * kWave + lane;                  /* element p: row p / TT, column p % TT */
+            const int r = p / TT, c = p % TT;
+            const int cr = __shfl(chan, r, kWave);
+            double v = 0.0;
+            if (g0 + r < g.count && c < cnt) v = io.in[(size_t)cr * io.ld_in + t0 + c];
+            *reinterpret_cast<double *>(smem + r * kRowBytes + c * 8) = v;
+        }
+        wave_sync();
+        for (int k = 0; k < cnt; ++k) {
+            double *px = reinterpret_cast<double *>(row + k * 8);
+            one_sample(*px);
+            *px = y;
+        }
+        wave_sync();
+        for (int i = 0; i < kLoads * 2; ++i) {
+            const int p = i * kWave + lane;
+            const int r = p / TT, c = p % TT;
+            const int cr = __shfl(chan, r, kWave);
+            if (g0 + r < g.count && c < cnt)
+                io.out[(size_t)cr * io.ld_out + t0 + c] = *reinterpret_cast<const double *>(smem + r * kRowBytes + c * 8);
+        }
+        wave_sync();
+    }
+
+    if (live) {
+        double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (i < K) st[i] = s[i];
+        g.fval[gi] = y;
+        g.init[gi] = ini;
+    }
+}
+
+/* Lane-per-channel kernel: when every filter of the group fits its registers, the bank is wide enough to
+ * fill the GPU with lanes and the block is too short to give the time-split kernels whole segments. */
+constexpr int kFirSeqMaxTaps = 32;
+constexpr int kFirSeqMinChannels = 16384;
+constexpr size_t kFirSeqMaxBlock = 4096;
+
+static hipError_t launch_fir_seq(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    const int blocks = (g.count + kWave - 1) / kWave;
+    const size_t lds = (size_t)kWave * (32 * 8 + 16);
+    const bool uni = g.single_design >= 0;
+    if (g.kmax <= 8) {
+        if (uni) hipLaunchKernelGGL((fir_seq_kernel<8, true>), dim3(blocks), dim3(kWave), lds, s, g, io);
+        else hipLaunchKernelGGL((fir_seq_kernel<8, false>), dim3(blocks), dim3(kWave), lds, s, g, io);
+    } else if (g.kmax <= 16) {
+        if (uni) hipLaunchKernelGGL((fir_seq_kernel<16, true>), dim3(blocks), dim3(kWave), lds, s, g, io);
+        else hipLaunchKernelGGL((fir_seq_kernel<16, false>), dim3(blocks), dim3(kWave), lds, s, g, io);
+    } else {
+        hipLaunchKernelGGL((fir_seq_kernel<32, true>), dim3(blocks), dim3(kWave), lds, s, g, io);
+    }
+    return hipGetLastError();
+}
+
+bool fir_uses_state_swap(const GroupView &g, const BlockIO &io)
+{
+    /* mixed designs keep their taps in vector registers: that fits up to 16 slots */
+    const int max_taps = g.single_design >= 0 ? kFirSeqMaxTaps : 16;
+    return !(g.kmax <= max_taps && g.count >= kFirSeqMinChannels && io.n <= kFirSeqMaxBlock);
+}
+
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
+    if (!fir_uses_state_swap(g, io)) return launch_fir_seq(g, io, s);      /* updates g.state in place */
     const int nseg = (int)((io.n + S - 1) / S);
     const int pro_blocks = (g.count + 255) / 256;
     hipLaunchKernelGGL(fir_prologue_kernel, dim3(pro_blocks), dim3(256), 0, s, g, io);

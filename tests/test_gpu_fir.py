@@ -187,3 +187,37 @@ def test_fir_very_long_filters_both_modes(G, K):
         st = bank.get_state()[0]
         assert util.bits_equal(st[:, :K], np.stack([r.state for r in ref]))
         bank.close()
+
+
+@pytest.mark.parametrize("mode_name", ["sequential", "auto"])
+@pytest.mark.parametrize("layout", ["mixed<=16", "uniform32", "uniform32-ramp"])
+def test_fir_short_blocks_on_a_wide_bank_lane_per_channel(G, mode_name, layout):
+    """>= 16384 channels, filters of <= 32 taps (<= 16 when designs are mixed), blocks of <= 4096 samples: the
+    lane-per-channel kernel (the reference's loop itself, in both modes) -- stable_init, partial_init ramps
+    running across block boundaries, a one-tap filter, ragged last wavefront, ragged tiles.  Bit-exact, state
+    included; longer blocks then continue on the time-split kernels from the same state."""
+    from dsp_amd import bank as gbank
+    if layout == "mixed<=16":
+        designs = [G.golden_design("fir7_lp_0.4"), G.golden_design("mavg3"), gbank.fir_design(np.array([0.75])),
+                   gbank.fir_design(np.random.default_rng(5).standard_normal(16) / 16, partial=True),
+                   gbank.fir_design(np.random.default_rng(6).standard_normal(13) / 13)]
+    elif layout == "uniform32":
+        designs = [G.golden_design("fir32_lp_0.25")]
+    else:
+        designs = [G.golden_design("mavg32")]
+    nch = 16384 + 37
+    idx = [(c * 7 + c // 64) % len(designs) for c in range(nch)]
+    mode = gbank.MODE_SEQUENTIAL if mode_name == "sequential" else gbank.MODE_AUTO
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, [1, 31, 33, 256, 700], mode, seed=91)
+    for i, (yg, yo) in enumerate(zip(ys_g, ys_o)):
+        assert util.bits_equal(yg, yo), i
+    G.assert_state_equal(gb, ob, exact=True)
+    x = G.make_inputs(92, nch, 5000)
+    yg = gb(G.to_dev(x)).cpu().numpy()
+    yo = ob.updaten(x, threads=8)
+    if mode_name == "sequential" or layout == "mixed<=16":
+        assert util.bits_equal(yg, yo)
+    else:
+        assert np.all(util.rel_to_peak(yg, yo) <= TOL_MFMA)
+    st = gb.get_state()[0]
+    assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state)

@@ -6,13 +6,13 @@ import numpy as np
 import torch
 from dsp_amd import bank as gbank
 
-C_, B = 8192, 1 << 16
+C_, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8192, 1 << 16)
 pitch = B + 128
 xb = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
 yb = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
 gbank.synth_fill(xb[:, :B], 1)
 rng = np.random.default_rng(0)
-for K in (2, 4, 8, 12, 16, 24, 32, 48, 64, 128):
+for K in ((2, 4, 8, 12, 16, 24, 32, 48, 64, 128) if len(sys.argv) <= 3 else [int(v) for v in sys.argv[3:]]):
     taps = rng.standard_normal(K) / K
     res = []
     for mode in (gbank.MODE_SEQUENTIAL, gbank.MODE_AUTO):
