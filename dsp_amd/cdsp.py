@@ -132,6 +132,10 @@ _proto("RTFilter_reset", None, [POINTER(RTFilter_)])
 _proto("RTIIRFilter_print", None, [POINTER(RTIIRFilter_)])
 _proto("RTFIRFilter_print", None, [POINTER(RTFIRFilter_)])
 
+# ---- include/filterutils.h (ref: python/cdsp.py:73-74 binds filter_response_pzg_noc at import) --------
+_proto("filter_response_pzg_noc", c_int, [_dp, _dp, c_size_t, _dp, _dp, c_size_t, _dp, _dp, c_size_t, c_double, _dp])
+_proto("filter_response_ab_noc", c_int, [_dp, _dp, c_size_t, _dp, c_size_t, _dp, c_size_t, _dp])
+
 # ---- include/RTFilterBank.h -------------------------------------------------------------------
 RTFB_OK, RTFB_EINVAL, RTFB_ESIZE, RTFB_EUNSUPPORTED, RTFB_EDEVICE, RTFB_ENOMEM = range(6)
 RTFB_KIND_IIR, RTFB_KIND_FIR, RTFB_KIND_FIR_PARTIAL = 0, 1, 2

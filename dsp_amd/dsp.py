@@ -183,3 +183,25 @@ def moving_average(window, initialize=None):
     if status:
         raise ValueError("moving_average: status %d" % status)
     return rtff
+
+
+def filter_response_pzg(poles, zeros, kgain=1, freqs=None, n=200):
+    """(gain, phase, freqs) of kgain * prod (z - zero_j) / (z - pole_j) at z = exp(i f); poles and zeros as
+    (re, im) pairs.  Mirror of the reference's python/dsp.py:126-144 (same default grid i/(n-1))."""
+    from ctypes import c_double, c_size_t
+    if freqs is None:
+        df = 1.0 / (n - 1)
+        freqs = list(i * df for i in range(n))
+    else:
+        n = len(freqs)
+    c_freqs = (c_double * n)(*freqs)
+    npoles, nz = len(poles), len(zeros)
+    c_poles_r = (c_double * npoles)(*[p[0] for p in poles])
+    c_poles_i = (c_double * npoles)(*[p[1] for p in poles])
+    c_zeros_r = (c_double * nz)(*[z[0] for z in zeros])
+    c_zeros_i = (c_double * nz)(*[z[1] for z in zeros])
+    c_gain = (c_double * n)()
+    c_phase = (c_double * n)()
+    dspdll.filter_response_pzg_noc(c_gain, c_phase, c_size_t(n), c_zeros_r, c_zeros_i, c_size_t(nz), c_poles_r,
+                                   c_poles_i, c_size_t(npoles), c_double(kgain), c_freqs)
+    return list(c_gain), list(c_phase), freqs

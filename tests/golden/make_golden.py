@@ -5,7 +5,7 @@ Run once in the build container (where /root/reference exists):
 
     make -C oracle ref && python tests/golden/make_golden.py
 
-Writes tests/golden/{kats.json, designs.json, runs.npz, demo.npz, errors.json}.
+Writes tests/golden/{kats.json, designs.json, runs.npz, demo.npz, errors.json, response.json}.
 Everything written is DATA (inputs, coefficient bit patterns, outputs, state
 snapshots); no reference source text is stored.  The GPU box has no reference,
 so tests there read only these files.
@@ -241,8 +241,45 @@ def make_errors():
     return out
 
 
+def make_response():
+    """filter_response_pzg_noc of the reference (src/filterutils.c:137-191), always with a caller's grid -- as the
+    reference's own python/dsp.py:126-143 calls it.  With freq == NULL the reference allocates room for ONE
+    double behind its complex scratch and then writes ng of them (src/filterutils.c:151-161): heap corruption,
+    so that path has no golden (the rebuilt library builds the same default grid in memory of its own)."""
+    L = ref.lib()
+    dp = C.POINTER(C.c_double)
+    L.filter_response_pzg_noc.argtypes = [dp, dp, C.c_size_t, dp, dp, C.c_size_t, dp, dp, C.c_size_t, C.c_double, dp]
+    L.filter_response_pzg_noc.restype = C.c_int
+    rng = np.random.default_rng(20240)
+    cases = {}
+    for name, nz, npoles, ng, own_grid in (("z3p4", 3, 4, 33, True), ("z4p2", 4, 2, 17, True),
+                                           ("z0p5", 0, 5, 9, True), ("z2p0", 2, 0, 8, True)):
+        zr, zi = rng.uniform(-1, 1, nz), rng.uniform(-1, 1, nz)
+        pr, pi = rng.uniform(-0.9, 0.9, npoles), rng.uniform(-0.9, 0.9, npoles)
+        freq = np.sort(rng.uniform(0, np.pi, ng))
+        if name == "z3p4":                         # the grid python/dsp.py builds: i * 1/(n-1)
+            freq = np.array([i * (1.0 / (ng - 1)) for i in range(ng)])
+        gain, phase = np.zeros(ng), np.zeros(ng)
+        k = 0.75
+        rc = L.filter_response_pzg_noc(gain.ctypes.data_as(dp), phase.ctypes.data_as(dp), ng,
+                                       zr.ctypes.data_as(dp), zi.ctypes.data_as(dp), nz,
+                                       pr.ctypes.data_as(dp), pi.ctypes.data_as(dp), npoles, k,
+                                       freq.ctypes.data_as(dp) if own_grid else None)
+        cases[name] = dict(status=rc, ng=ng, kgain=float(k).hex(), zeros_r=hexes(zr), zeros_i=hexes(zi),
+                           poles_r=hexes(pr), poles_i=hexes(pi), freq=hexes(freq) if own_grid else None,
+                           gain=hexes(gain), phase=hexes(phase))
+    g1 = np.zeros(1)
+    cases["errors"] = dict(null_gain=L.filter_response_pzg_noc(None, g1.ctypes.data_as(dp), 1, None, None, 0, None,
+                                                               None, 0, 1.0, None),
+                           ng0=L.filter_response_pzg_noc(g1.ctypes.data_as(dp), g1.ctypes.data_as(dp), 0, None, None,
+                                                         0, None, None, 0, 1.0, None))
+    return cases
+
+
 def main():
     assert ref.available(), "build oracle/_ref first: make -C oracle ref"
+    with open(os.path.join(HERE, "response.json"), "w") as fh:
+        json.dump(make_response(), fh, indent=1, sort_keys=True)
     kats = make_kats()
     designs = make_designs()
     with open(os.path.join(HERE, "kats.json"), "w") as fh:

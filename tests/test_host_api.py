@@ -30,7 +30,7 @@ def test_struct_layouts_match_reference_abi():
 
 def test_every_declared_symbol_is_exported():
     names = set()
-    for hdr in ("RTFilter.h", "RTFilterBank.h", "RTFilterStream.h"):
+    for hdr in ("RTFilter.h", "RTFilterBank.h", "RTFilterStream.h", "filterutils.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"EXPORT\s+[\w\s\*]+?\b(\w+)\s*\(", text))
