@@ -37,6 +37,21 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.2
 BYTES_PER_SAMPLE = 16            # 8 B read x + 8 B write y
 
 
+def _init_dist(dist, local):
+    """RCCL (backend "nccl") with one rank per GPU.  BENCH_DIST_BACKEND=gloo together with BENCH_ONE_GPU=1 is a
+    rehearsal switch: several ranks share cuda:0 (RCCL refuses that) so that the N > 1 code path of this script
+    can be exercised on a one-GPU box; it is never what the driver runs."""
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+
+
+def _reduce_device(dist, dev):
+    return dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def cpu_baseline(b, a):
     """Reference (oracle/_ref, if it travelled) or the oracle port, on the host cores: every thread
     filters CHANNELS/threads channels of 2^20 samples with its own filter object."""
@@ -126,11 +141,11 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        _init_dist(dist, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -178,7 +193,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_reduce_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -245,11 +260,11 @@ def main_fir512(args):
     TAPS = 512
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        _init_dist(dist, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from dsp_amd import bank as gbank
@@ -288,7 +303,7 @@ def main_fir512(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_reduce_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in events]
@@ -335,11 +350,11 @@ def main_mixed(args):
     consumer's view); the sample blocks themselves stay sharded."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        _init_dist(dist, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from dsp_amd import bank as gbank
@@ -408,7 +423,7 @@ def main_mixed(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_reduce_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = np.array([e0.elapsed_time(e1) for e0, e1 in events])
@@ -452,11 +467,11 @@ def main_stream16(args):
     chunks concurrently => STRONG scaling (total work fixed).  Consecutive steps continue the stream."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        _init_dist(dist, local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from dsp_amd import bank as gbank
@@ -501,7 +516,7 @@ def main_stream16(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_reduce_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = [e0.elapsed_time(e1) for e0, e1 in events]
