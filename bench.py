@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--mode", choices=["auto", "scan", "seq"], default="auto")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--jitter", action="store_true",
+                    help="config 2 variant of SURVEY.md 8(d): every channel its own butterworth(4, wl, wu), band edges "
+                         "jittered inside [0.25, 0.65], so that no coefficient table is shared")
     ap.add_argument("--workload", choices=["iir8", "fir512", "stream16", "mixed"], default="iir8",
                     help="iir8 = BASELINE.json config 2 (the headline line); fir512 = config 3; "
                          "stream16 = config 5 (one 2^30-sample stream, 16th-order IIR, split in time)")
@@ -153,7 +156,17 @@ def main():
     from tests import util
     _, b, a = util.design_coefs(DESIGN)
     mode = dict(auto=gbank.MODE_AUTO, scan=gbank.MODE_SCAN, seq=gbank.MODE_SEQUENTIAL)[args.mode]
-    bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
+    if args.jitter:
+        from dsp_amd import dsp
+        rng = np.random.default_rng(SEED + rank)
+        designs = []
+        for c in range(CHANNELS):
+            wl = 0.25 + 0.1 * rng.random()
+            f = dsp.butterworth(4, wl, wl + 0.25 + 0.05 * rng.random())
+            designs.append(gbank.iir_design(np.array(f.b()), np.array(f.a())))
+        bank = gbank.FilterBank(designs, list(range(CHANNELS)), device=local, mode=mode)
+    else:
+        bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
 
     xbuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
     ybuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
@@ -234,7 +247,8 @@ def main():
                                    "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
-                       "row_pitch_doubles": PITCH, "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
+                       "row_pitch_doubles": PITCH, "distinct_designs": CHANNELS if args.jitter else 1,
+                       "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,
