@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""profiles/r1_traffic.json and profiles/r1_fir512_traffic.json from the tools/prof.sh summaries
+(profiles/r1_config2_rocprofv3_summary.txt, profiles/r1_config3_rocprofv3_summary.txt)."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORR = ("MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
+        "coalesced streaming read -> doubled; WRITE_SIZE exact for 16 B/lane streaming stores")
+
+
+def sections(path):
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"== (\w+): per-launch mean of each counter ==\n(.*?)(?=\n== |\Z)", txt, re.S):
+        per, k = {}, None
+        for line in m.group(2).splitlines():
+            if line.startswith(("dsp::", "void dsp::")):
+                k = line.strip()
+                per[k] = {}
+            mm = re.match(r"\s+(\w+)\s+n=\d+\s+mean=([\d.e+-]+)", line)
+            if mm and k:
+                per[k][mm.group(1)] = float(mm.group(2))
+        out[m.group(1)] = per
+    return out
+
+
+def pick(per, needle):
+    return [v for k, v in per.items() if needle in k]
+
+
+def main():
+    s2 = sections(os.path.join(ROOT, "profiles", "r1_config2_rocprofv3_summary.txt"))
+    f = pick(s2["pmc_fetch"], "iir_pipe_kernel")[0]["FETCH_SIZE"]
+    w = pick(s2["pmc_write"], "iir_pipe_kernel")[0]["WRITE_SIZE"]
+    hbm = int(f * 1024 * 2 + w * 1024)
+    alg = 1024 * 65536 * 16
+    json.dump({"kernel": "dsp::iir_pipe_kernel<8, true>",
+               "source": "profiles/r1_config2_rocprofv3_summary.txt (tools/prof.sh: rocprofv3 --pmc FETCH_SIZE "
+                         "GRBM_GUI_ACTIVE ; --pmc WRITE_SIZE ; bench.py --steps 32 --warmup 8 --no-cpu)",
+               "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "correction": CORR,
+               "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
+               "traffic_over_algorithmic": hbm / alg},
+              open(os.path.join(ROOT, "profiles", "r1_traffic.json"), "w"), indent=1)
+    s3 = sections(os.path.join(ROOT, "profiles", "r1_config3_rocprofv3_summary.txt"))
+    tot_f = sum(v["FETCH_SIZE"] for k, v in s3["pmc_fetch"].items() if "fir_" in k)
+    tot_w = sum(v["WRITE_SIZE"] for k, v in s3["pmc_write"].items() if "fir_" in k)
+    steady = pick(s3["pmc_mfma"], "fir_mfma_kernel<")[0]
+    hbm3 = int(tot_f * 1024 * 2 + tot_w * 1024)
+    alg3 = 65536 * 65536 * 16
+    json.dump({"kernels": "fir_prologue + fir_mfma_edge + fir_mfma_kernel<true> + fir_epilogue (one step of config 3)",
+               "source": "profiles/r1_config3_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
+                         "bench.py --workload fir512 --steps 3 --warmup 1 --no-cpu)",
+               "FETCH_SIZE_KiB_per_step": tot_f, "WRITE_SIZE_KiB_per_step": tot_w, "correction": CORR,
+               "hbm_bytes_per_launch": hbm3, "algorithmic_bytes_per_launch": alg3,
+               "traffic_over_algorithmic": hbm3 / alg3,
+               "note": "bound is FP64 MFMA, not HBM; the extra reads are the 528-sample halo of every 4096-output item",
+               "mfma_busy_cycles_steady_kernel": steady["SQ_VALU_MFMA_BUSY_CYCLES"],
+               "grbm_gui_active_steady_kernel_sum_over_8_xcd": steady["GRBM_GUI_ACTIVE"],
+               "mfma_pipe_utilisation_steady_kernel":
+                   steady["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * steady["GRBM_GUI_ACTIVE"] / 8)},
+              open(os.path.join(ROOT, "profiles", "r1_fir512_traffic.json"), "w"), indent=1)
+    for n in ("r1_traffic.json", "r1_fir512_traffic.json"):
+        print(n, json.load(open(os.path.join(ROOT, "profiles", n)))["traffic_over_algorithmic"])
+
+
+if __name__ == "__main__":
+    main()
