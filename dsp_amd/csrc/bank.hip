@@ -598,7 +598,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             if ((rc = upload(&g.d_aux, aux, device))) return rc;
         }
         if (g.cls == kIirFast && std::getenv("DSP_AMD_SCAN_STAMPS")) {   /* diagnostics only */
-            std::vector<int32_t> dbg(16 * cnt, 0);
+            std::vector<int32_t> dbg(64 * cnt, 0);
             if ((rc = upload(&g.d_aux, dbg, device))) return rc;
         }
         if ((rc = upload(&g.d_fval, fv, device))) return rc;
@@ -1004,7 +1004,7 @@ int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, si
 }
 
 /* Diagnostics (DSP_AMD_SCAN_STAMPS=1): copy the scan kernel's per-channel phase-cycle sums
- * (8 uint64 per channel of the first fast-IIR group) to the host. Not declared in the headers. */
+ * (32 uint64 per channel of the first fast-IIR group; scan2 uses a stride of 8) to the host. Not declared in the headers. */
 EXPORT int dsp_debug_scan_stamps(RTFilterBank *bank, uint64_t *dst, size_t nwords)
 {
     if (!bank || !dst) return fail(RTFB_EINVAL, "NULL argument");
@@ -1012,7 +1012,7 @@ EXPORT int dsp_debug_scan_stamps(RTFilterBank *bank, uint64_t *dst, size_t nword
     HIP_TRY(hipDeviceSynchronize());
     for (const Group &g : bank->groups)
         if (g.cls == kIirFast && g.d_aux) {
-            const size_t have = g.chans.size() * 8;
+            const size_t have = g.chans.size() * 32;
             HIP_TRY(hipMemcpy(dst, g.d_aux, std::min(have, nwords) * 8, hipMemcpyDeviceToHost));
             return RTFB_OK;
         }

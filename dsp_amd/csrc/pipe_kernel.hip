@@ -47,13 +47,12 @@ constexpr int kPLevels = 6;                 /* log2(64) */
 
 template <int N, bool kUnitA0>
 __global__ void __launch_bounds__(2 * kWave, 2)
-iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
+iir_pipe_kernel(GroupView g, BlockIO io)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile0 = smem;
     char *tile1 = smem + kPTile;
-    double *mats = reinterpret_cast<double *>(smem + 2 * kPTile);    /* lds_levels x N x N, column-major */
-    double *pbuf = mats + lds_levels * N * N;                         /* 64 x N start states */
+    double *pbuf = reinterpret_cast<double *>(smem + 2 * kPTile);    /* 64 x N start states */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,6 +63,17 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
     int nlev = as_const(g.levels2)[dsn];
     if (nlev > kPLevels) nlev = kPLevels;
 
+    /* diagnostics (DSP_AMD_SCAN_STAMPS=1 allocates g.aux): 100 MHz timestamps of one workgroup's milestones */
+    unsigned long long *dbg = g.aux ? reinterpret_cast<unsigned long long *>(g.aux) + (size_t)gi * 32 : nullptr;
+    if (dbg && lane == 0 && front) {
+        dbg[0] = __builtin_amdgcn_s_memrealtime();
+        dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        /* HW_ID: simd, cu, sh, se */
+        dbg[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       /* XCC_ID */
+        dbg[16] = __builtin_amdgcn_s_memtime();                    /* shader clock, with [17] */
+    }
+    auto stamp = [&](int slot) {
+        if (dbg && lane == 0) dbg[slot] = __builtin_amdgcn_s_memrealtime();
+    };
     const size_t n = io.n;
     const int nseg = (int)((n + kPSeg - 1) / kPSeg);
     const double *src = io.in + (size_t)chan * io.ld_in;
@@ -98,25 +108,19 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
     if (front) {
         fetch(0, pre0);
         fetch(1, pre1);
-        /* Warm the scalar cache: the zero-state pass reads the response table G through scalar loads, one
-         * 64-byte line after the other as its loop advances; cold, every line is a separate trip to L2
-         * (~18 us per launch for a 2 KB table).  Touch all lines now, back to back. */
+        /* Warm the scalar cache: the front wave reads its two tables -- the zero-state response G and the
+         * prefix matrices A^(32 2^k) -- through scalar loads, one 64-byte line after the other as its loops
+         * advance; cold, every line is a separate trip to L2 (~18 us per launch for a 2 KB table).  Touch
+         * all lines now, back to back. */
         cint_p gw = (cint_p)(uintptr_t)(g.pows + as_const(g.gtab_off)[dsn]);
         int touched = 0;
 #pragma unroll
         for (int l = 0; l < ((PT + 1) * N * 8 + 63) / 64; ++l) touched |= gw[l * 16];
+        cint_p mw = (cint_p)(uintptr_t)(g.pows + as_const(g.pow2_off)[dsn]);
+        for (int l = 0; l < (nlev * N * N * 8 + 63) / 64; ++l) touched |= mw[l * 16];
         asm volatile("" ::"s"(touched));
     }
-
-    /* matrix powers of this design -> LDS, transposed to column-major */
-    {
-        const double *pw = g.pows + g.pow2_off[dsn];
-        for (int e = tid; e < nlev * N * N; e += 2 * kWave) {
-            const int lvl = e / (N * N), r = e % (N * N);
-            mats[lvl * N * N + (r % N) * N + (r / N)] = pw[e];
-        }
-        if (tid < N) pbuf[tid] = 0.0;                       /* row 0 never receives a prefix */
-    }
+    if (tid < N) pbuf[tid] = 0.0;                           /* row 0 never receives a prefix */
 
     /* staging geometry (both roles): piece p = i*64 + lane -> row i*4 + (lane>>4), column lane&15 */
     const int st_r = lane >> 4;
@@ -126,22 +130,26 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
         st_addr[v] = st_r * (PT * 8) + (((lane & 15) ^ (v * 4 + st_r)) << 4);
     const int rx = (lane & 15) << 4;
 
-    double b[N + 1], a[N + 1];
-    {
+    /* coefficients live in SGPRs; the front wave only needs them for the seeded first row and loads them
+     * there, so that its scalar registers stay free for the table batches */
+    auto load_coefs = [&](double(&b)[N + 1], double(&a)[N + 1]) {
         cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
 #pragma unroll
         for (int i = 0; i <= N; ++i) {
             b[i] = cf[i];
             a[i] = cf[N + 1 + i];
         }
-    }
+    };
     const double tail0 = g.state[(size_t)gi * g.state_ld + N];   /* s[N]: read, never written */
 
     if (front) {
         /* =============================== FRONT =============================== */
         cdouble_p gtab = as_const(g.pows) + as_const(g.gtab_off)[dsn];
+        cdouble_p ptab = as_const(g.pows) + as_const(g.pow2_off)[dsn];      /* [level][i][j], row-major */
         auto front_step = [&](int it, d2(&pre)[kPPieces]) {
             char *tile = (it & 1) ? tile1 : tile0;
+            if (it == 0) stamp(1);                            /* set-up done */
+            if (it == 8) stamp(11);
             lds_barrier();                                    /* barrier 0 */
             if (it < nseg) {
 #pragma unroll
@@ -150,6 +158,8 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             }
             lds_barrier();                                    /* barrier 1 */
             if (it >= nseg) return;
+            if (it == 0) stamp(7);
+            if (it == 8) stamp(12);
             fetch(it + 2, pre);
 
             const bool seeded = seed_stream && it == 0;
@@ -159,21 +169,40 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = 0.0;
             v[N] = tailv;
-#pragma unroll 2
-            for (int q = 0; q < PT / 2; ++q) {
-                const d2 xv = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+            /* the row comes out of LDS in one burst; the table arrives in scalar batches of kZB samples
+             * (<= 32 SGPRs each), so a batch's wait is not also a wait for LDS */
+            d2 xr[PT / 2];
 #pragma unroll
-                for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[(2 * q) * N + i], xv.x, v[i]);
+            for (int q = 0; q < PT / 2; ++q) xr[q] = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+            constexpr int kZB = N <= 4 ? 4 : 2;
 #pragma unroll
-                for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[(2 * q + 1) * N + i], xv.y, v[i]);
+            for (int k0 = 0; k0 < PT; k0 += kZB) {
+                double gk[kZB][N];
+#pragma unroll
+                for (int k = 0; k < kZB; ++k) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) gk[k][i] = gtab[(k0 + k) * N + i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < kZB; ++k) {
+                    const double xk = ((k0 + k) & 1) ? xr[(k0 + k) >> 1].y : xr[(k0 + k) >> 1].x;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gk[k][i], xk, v[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (tailv != 0.0) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[PT * N + i], tailv, v[i]);
             }
+            if (it == 0) stamp(8);
+            if (it == 8) stamp(13);
             if (seeded && lane == 0) {
                 /* row 0 of a fresh stream: RTIIRFilter_stable_init on sample 0, then the recurrence;
                  * its end state does not depend on any carried state */
+                double b[N + 1], a[N + 1];
+                load_coefs(b, a);
 #pragma unroll
                 for (int i = 0; i <= N; ++i) v[i] = 0.0;
                 const size_t left = n < (size_t)PT ? n : (size_t)PT;
@@ -183,34 +212,32 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
                         *reinterpret_cast<const double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8), v, b, a);
             }
 
-            /* Kogge-Stone over the 64 rows, zero carry-in */
+            /* Kogge-Stone over the 64 rows, zero carry-in.  The level's matrix A^(32 d) is wave-uniform: it
+             * comes through the scalar cache in batches of kKR rows (<= 64 SGPRs), not through LDS, whose
+             * pipe the two roles' tile traffic already keeps busy. */
             for (int lvl = 0; lvl < nlev; ++lvl) {
                 const int d = 1 << lvl;
-                const double *M = mats + lvl * N * N;
-                constexpr int kAhead = N < 3 ? N : 3;
-                double mc[kAhead][N];
-#pragma unroll
-                for (int c = 0; c < kAhead; ++c) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) mc[c][i] = M[c * N + i];
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 double u[N];
 #pragma unroll
-                for (int i = 0; i < N; ++i) u[i] = __shfl_up(v[i], d, kWave);
+                for (int i = 0; i < N; ++i) {
+                    const double t = __shfl_up(v[i], d, kWave);
+                    u[i] = lane >= d ? t : 0.0;
+                }
+                constexpr int kKR = N <= 4 ? N : 4;
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    double col[N];
+                for (int r0 = 0; r0 < N; r0 += kKR) {
+                    double m[kKR][N];
 #pragma unroll
-                    for (int i = 0; i < N; ++i) col[i] = mc[j % kAhead][i];
-                    if (j + kAhead < N) {
+                    for (int r = 0; r < kKR; ++r) {
 #pragma unroll
-                        for (int i = 0; i < N; ++i) mc[j % kAhead][i] = M[(j + kAhead) * N + i];
+                        for (int j = 0; j < N; ++j) m[r][j] = (r0 + r < N) ? ptab[(lvl * N + r0 + r) * N + j] : 0.0;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (lane >= d) {
 #pragma unroll
-                        for (int i = 0; i < N; ++i) v[i] = __builtin_fma(col[i], u[j], v[i]);
+                    for (int j = 0; j < N; ++j) {
+#pragma unroll
+                        for (int r = 0; r < kKR; ++r)
+                            if (r0 + r < N) v[r0 + r] = __builtin_fma(m[r][j], u[j], v[r0 + r]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -221,6 +248,11 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
 #pragma unroll
                 for (int i = 0; i < N; ++i) slot[i] = v[i];
             }
+            if (it == 0) stamp(2);                            /* segment 0 published */
+            if (it == 8) {
+                stamp(14);
+                if (dbg && lane == 0) dbg[17] = __builtin_amdgcn_s_memtime();
+            }
         };
 
         for (int it = 0; it <= nseg; it += 2) {
@@ -229,6 +261,8 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
         }
     } else {
         /* =============================== BACK ================================ */
+        double b[N + 1], a[N + 1];
+        load_coefs(b, a);
         double carry[N + 1];
         {
             const double *st = g.state + (size_t)gi * g.state_ld;
@@ -244,6 +278,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             for (int e = 0; e < N * N; ++e) tp[e] = tt[e * kWave];
         }
 
+        stamp(9);
         for (int it = 0; it <= nseg; ++it) {
             const int seg = it - 1;
             char *tile = (seg & 1) ? tile1 : tile0;
@@ -256,6 +291,8 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             }
             lds_barrier();                                    /* barrier 1 */
             if (seg < 0) continue;
+            if (seg == 0) stamp(3);                           /* back starts segment 0 */
+            if (seg == 8) stamp(15);
 
             const size_t base = (size_t)seg * kPSeg;
             const size_t left = n - base;
@@ -278,9 +315,13 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             char *row = tile + lane * (PT * 8);
             double y = ylast;
             if (fast) {
-#pragma unroll 4
+                /* the whole row in one burst of LDS reads, then arithmetic only */
+                d2 xr[PT / 2];
+#pragma unroll
+                for (int q = 0; q < PT / 2; ++q) xr[q] = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+#pragma unroll
                 for (int q = 0; q < PT / 2; ++q) {
-                    d2 xv = *reinterpret_cast<d2 *>(row + ((q << 4) ^ rx));
+                    d2 xv = xr[q];
                     xv.x = iir_step_fused<N, kUnitA0>(xv.x, s, b, a);
                     xv.y = y = iir_step_fused<N, kUnitA0>(xv.y, s, b, a);
                     *reinterpret_cast<d2 *>(row + ((q << 4) ^ rx)) = xv;
@@ -307,6 +348,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             ylast = __shfl(y, jlast, kWave);
 
             /* store the segment, coalesced (this wave wrote the whole tile: in-order LDS) */
+            if (seg == 0) stamp(10);
             wave_sync();
             if (seg_len == kPSeg && io.aligned16) {
 #pragma unroll 8
@@ -330,6 +372,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
             for (int i = 0; i <= N; ++i) st[i] = carry[i];
             g.fval[gi] = ylast;
             g.init[gi] = 0;
+            if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();                            /* back done */
         }
     }
 }
@@ -337,12 +380,11 @@ iir_pipe_kernel(GroupView g, BlockIO io, int lds_levels)
 template <int N>
 static hipError_t launch_pipe_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
-    int levels = g.levels2_max > kPLevels ? kPLevels : g.levels2_max;
-    const size_t lds = 2 * kPTile + sizeof(double) * ((size_t)levels * N * N + (size_t)kPRows * N);
+    const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * N;
     if (g.unit_a0)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, levels);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
     else
-        hipLaunchKernelGGL((iir_pipe_kernel<N, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, levels);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
     return hipGetLastError();
 }
 
