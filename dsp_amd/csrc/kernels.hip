@@ -16,6 +16,7 @@
  * back with coalesced 16-byte stores.  HBM sees each sample once in, once out:
  * 16 B/sample, the algorithmic minimum.
  */
+#include <cstdlib>
 #include "dsp_internal.h"
 #include "kernel_common.h"
 #include "iir_steps.h"
@@ -479,6 +480,346 @@ iir_scan_kernel(GroupView g, BlockIO io)
 }
 
 /* ------------------------------------------------------------------------ */
+/* K_scan16: orders 9..16, the scan kernel with its two GEMM-shaped stages on */
+/* the FP64 matrix cores (v_mfma_f64_16x16x4_f64).                             */
+/*                                                                            */
+/* For these orders the per-design tables of K_scan (zero-state response G:   */
+/* 65 x N doubles, prefix matrices A^(64 2^k): 6 x N x N) no longer fit the    */
+/* scalar cache next to each other, and with one wavefront per SIMD (the 33 KB */
+/* tile limits a CU to four channels) every table batch is an exposed trip to  */
+/* L2: pass 1 and the combine ran at a third of their issue rate.  Here both    */
+/* tables live in VGPRs for the whole launch, in MFMA operand layout, and no    */
+/* table is read inside the segment loop:                                       */
+/*   pass 1   V^T (16 states x 64 rows) = G^T (16 x 64 samples) X^T: 64 MFMAs,  */
+/*            A operand = G (resident), B operand = x straight from the tile    */
+/*   combine  Kogge-Stone level d:  V^T += M_d (16 x 16, resident) U^T, where   */
+/*            U = V shifted down d rows (row -1 = the carried state).  The      */
+/*            FP64 accumulator layout (register t of 16-lane group q = state    */
+/*            4t + q of the lane's row) IS the B layout of k-step t, so a level  */
+/*            is only the row shift -- a DPP row_shr with the wrap taken from    */
+/*            the previous 16-row block; d = 16, 32: a register renaming -- and  */
+/*            16 MFMAs                                                            */
+/*   pass 2   a 4x4 transpose between register index and lane group (two         */
+/*            v_permlane32_swap + two v_permlane16_swap per dword) turns the     */
+/*            prefix into row-per-lane start states; the recurrence runs on the  */
+/*            VALU as in K_scan                                                  */
+/* States above N are zero padding (zero columns of G, zero rows/columns of M). */
+/* Ragged or seeded segments take K_scan's general path.  Not bit-exact; same   */
+/* 1e-12 bar and admission rule as K_scan.                                      */
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lane_swap32(double &a, double &b)
+{
+    u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+__device__ __forceinline__ void lane_swap16(double &a, double &b)
+{
+    u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+/* element (register a, 16-lane group g) <-> (register g, group a) */
+__device__ __forceinline__ void transpose4(double &r0, double &r1, double &r2, double &r3)
+{
+    lane_swap32(r0, r2);
+    lane_swap32(r1, r3);
+    lane_swap16(r0, r1);
+    lane_swap16(r2, r3);
+}
+
+/* within every 16-lane group: lane r takes cur from lane r-D, lanes r < D take prev from lane r-D+16 */
+template <int D>
+__device__ __forceinline__ double row_shift(double cur, double prev)
+{
+    static_assert(D >= 1 && D <= 15, "row shift inside a 16-lane group");
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(prev), 0x120 + D, 0xf, 0xf, false);   /* row_ror:D */
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(prev), 0x120 + D, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(cur), 0x110 + D, 0xf, 0xf, false);       /* row_shr:D */
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(cur), 0x110 + D, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int LVL>
+__device__ __forceinline__ void scan16_level(d4 (&acc)[4], const double (&Mr)[4], const double (&cvirt)[4])
+{
+    constexpr int D = 1 << LVL;
+    /* accumulator register t of 16-lane group q holds state 4t + q: already the B layout of k-step t */
+    double tm[4][4];                                   /* [16-row block][k-step], unshifted */
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tm[rb][t] = acc[rb][t];
+    }
+    double u[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (D < 16)
+                u[rb][ks] = row_shift<(D < 16 ? D : 1)>(tm[rb][ks], rb ? tm[rb ? rb - 1 : 0][ks] : cvirt[ks]);
+            else if constexpr (D == 16)
+                u[rb][ks] = rb ? tm[rb ? rb - 1 : 0][ks] : cvirt[ks];
+            else
+                u[rb][ks] = rb >= 2 ? tm[rb >= 2 ? rb - 2 : 0][ks] : (rb == 1 ? cvirt[ks] : 0.0);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mr[ks], u[rb][ks], acc[rb], 0, 0, 0);
+    }
+}
+
+template <int N, int T, bool kUnitA0, bool kStamp = false>
+__global__ void __launch_bounds__(kWave)
+iir_scan16_kernel(GroupView g, BlockIO io)
+{
+    static_assert(T == 64 && N > 8 && N <= 16, "orders 9..16, 64-sample rows");
+    using TG = Tile<T>;
+    constexpr int kSeg = kWave * T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int gi = blockIdx.x;                       /* one wavefront per channel */
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+
+    double b[N + 1], a[N + 1], carry[N + 1];
+    {
+        cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            b[i] = cf[i];
+            a[i] = cf[N + 1 + i];
+        }
+        const double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) carry[i] = st[i];
+    }
+    cdouble_p pw = as_const(g.pows) + as_const(g.pow_off)[dsn];
+    cdouble_p gtab = as_const(g.pows) + as_const(g.gtab1_off)[dsn];
+    const int nlev = as_const(g.levels1)[dsn];
+    double ylast = g.fval[gi];
+    bool need_seed = g.init[gi] != 0;
+
+    /* resident MFMA operands of this design (A layout: row index = lane & 15, k = lane >> 4) */
+    double Gr[T / 4], Gt[4], Mr[kScanLevels][4];
+    {
+        const double *gt = g.pows + g.gtab1_off[dsn];
+        const double *pm = g.pows + g.pow_off[dsn];
+        const bool live = r16 < N;
+#pragma unroll
+        for (int ks = 0; ks < T / 4; ++ks) Gr[ks] = live ? gt[(4 * ks + q4) * N + (live ? r16 : 0)] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int st = 4 * t + q4;                                   /* accumulator layout */
+            Gt[t] = st < N ? gt[T * N + (st < N ? st : 0)] : 0.0;
+        }
+#pragma unroll
+        for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + q4;
+                const bool in = live && k < N;
+                Mr[lvl][ks] = in ? pm[lvl * N * N + (in ? r16 * N + k : 0)] : 0.0;
+            }
+        }
+    }
+
+    const size_t n = io.n;
+    const double *src = io.in + (size_t)chan * io.ld_in;
+    double *dst = io.out + (size_t)chan * io.ld_out;
+
+    d2 pre[TG::kLoads];
+    auto fetch = [&](size_t base) {
+        const size_t left = n - base;
+        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
+        if (seg_len == kSeg && io.aligned16) {
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i)
+                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+        } else {
+#pragma unroll
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int e = 2 * (i * kWave + lane);
+                d2 v = {0.0, 0.0};
+                if (e < seg_len) v.x = src[base + e];
+                if (e + 1 < seg_len) v.y = src[base + e + 1];
+                pre[i] = v;
+            }
+        }
+    };
+
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+    auto stamp = [&](int slot) {
+        if (kStamp) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            acc_t[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
+
+    fetch(0);
+    if (kStamp) t_prev = __builtin_readcyclecounter();
+    for (size_t base = 0; base < n; base += kSeg) {
+        const size_t left = n - base;
+        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
+
+        /* park the prefetched segment in LDS (row = lane-chunk, padded) */
+#pragma unroll
+        for (int i = 0; i < TG::kLoads; ++i) {
+            const int p = i * kWave + lane;
+            *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
+                                    (p % TG::kPiecesPerRow) * 16) = pre[i];
+        }
+        wave_sync();
+        stamp(0);
+        if (base + kSeg < n) fetch(base + kSeg);     /* next segment's loads fly during compute */
+        stamp(1);
+
+        if (seg_len == kSeg && !need_seed) {
+            const double tail = carry[N];
+            /* the carried state in B layout, as virtual row -1 (lane 15 of the block in front of block 0) */
+            double cvirt[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double c0 = 4 * ks + 0 < N ? carry[4 * ks + 0 < N ? 4 * ks + 0 : 0] : 0.0;
+                const double c1 = 4 * ks + 1 < N ? carry[4 * ks + 1 < N ? 4 * ks + 1 : 0] : 0.0;
+                const double c2 = 4 * ks + 2 < N ? carry[4 * ks + 2 < N ? 4 * ks + 2 : 0] : 0.0;
+                const double c3 = 4 * ks + 3 < N ? carry[4 * ks + 3 < N ? 4 * ks + 3 : 0] : 0.0;
+                const double cb = q4 == 0 ? c0 : (q4 == 1 ? c1 : (q4 == 2 ? c2 : c3));
+                cvirt[ks] = r16 == 15 ? cb : 0.0;
+            }
+
+            /* ---- pass 1: zero-state end vectors of the 64 rows ---- */
+            d4 acc[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[rb][t] = Gt[t] * tail;
+            }
+            const char *xb = smem + r16 * TG::kRowBytes + q4 * 8;
+#pragma unroll
+            for (int ks = 0; ks < T / 4; ++ks) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const double xv = *reinterpret_cast<const double *>(xb + rb * 16 * TG::kRowBytes + ks * 32);
+                    acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gr[ks], xv, acc[rb], 0, 0, 0);
+                }
+            }
+            stamp(2);
+
+            /* ---- prefix combine over the rows ---- */
+            if (nlev > 0) scan16_level<0>(acc, Mr[0], cvirt);
+            if (nlev > 1) scan16_level<1>(acc, Mr[1], cvirt);
+            if (nlev > 2) scan16_level<2>(acc, Mr[2], cvirt);
+            if (nlev > 3) scan16_level<3>(acc, Mr[3], cvirt);
+            if (nlev > 4) scan16_level<4>(acc, Mr[4], cvirt);
+            if (nlev > 5) scan16_level<5>(acc, Mr[5], cvirt);
+
+            /* end state after row j, row per lane */
+            double v[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double w0 = acc[0][t], w1 = acc[1][t], w2 = acc[2][t], w3 = acc[3][t];
+                transpose4(w0, w1, w2, w3);
+                v[4 * t + 0] = w0;                     /* register t of group q held state 4t + q */
+                v[4 * t + 1] = w1;
+                v[4 * t + 2] = w2;
+                v[4 * t + 3] = w3;
+            }
+            stamp(3);
+
+            /* ---- pass 2: true start state = end state of the row before ---- */
+            double s[N + 1];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double prev = shfl_up_f64(v[i], 1);
+                s[i] = (lane == 0) ? carry[i] : prev;
+            }
+            s[N] = tail;
+            char *row = smem + lane * TG::kRowBytes;
+            double y = ylast;
+            /* two register sets of 4 samples, each refilled right after it is consumed: the LDS read of
+             * one set is in flight while the other set's 4 x (2N+1) FMAs issue, and no set is ever copied */
+            auto run4 = [&](d2 &p0, d2 &p1, int k) {
+                p0.x = iir_step_fused<N, kUnitA0>(p0.x, s, b, a);
+                p0.y = iir_step_fused<N, kUnitA0>(p0.y, s, b, a);
+                p1.x = iir_step_fused<N, kUnitA0>(p1.x, s, b, a);
+                p1.y = y = iir_step_fused<N, kUnitA0>(p1.y, s, b, a);
+                *reinterpret_cast<d2 *>(row + k * 8) = p0;
+                *reinterpret_cast<d2 *>(row + k * 8 + 16) = p1;
+            };
+            d2 e0 = *reinterpret_cast<const d2 *>(row);
+            d2 e1 = *reinterpret_cast<const d2 *>(row + 16);
+#pragma unroll 1
+            for (int k = 0; k < T; k += 8) {
+                d2 o0 = *reinterpret_cast<const d2 *>(row + k * 8 + 32);
+                d2 o1 = *reinterpret_cast<const d2 *>(row + k * 8 + 48);
+                run4(e0, e1, k);
+                const int kn = (k + 8 < T) ? k + 8 : k;
+                e0 = *reinterpret_cast<const d2 *>(row + kn * 8);
+                e1 = *reinterpret_cast<const d2 *>(row + kn * 8 + 16);
+                run4(o0, o1, k + 4);
+            }
+            stamp(4);
+#pragma unroll
+            for (int i = 0; i <= N; ++i) carry[i] = shfl_f64(s[i], kWave - 1);
+            ylast = shfl_f64(y, kWave - 1);
+        } else {
+            scan_segment<N, T, kUnitA0, true, kStamp>(smem, lane, seg_len, need_seed, b, a, pw, gtab, nlev, carry,
+                                                      ylast, acc_t, t_prev);
+        }
+        need_seed = false;
+        wave_sync();
+
+        if (seg_len == kSeg && io.aligned16) {
+#pragma unroll 8
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int p = i * kWave + lane;
+                *reinterpret_cast<d2 *>(dst + base + 2 * p) = *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < TG::kLoads; ++i) {
+                const int p = i * kWave + lane;
+                const int e = 2 * p;
+                const d2 v = *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+                if (e < seg_len) dst[base + e] = v.x;
+                if (e + 1 < seg_len) dst[base + e + 1] = v.y;
+            }
+        }
+        wave_sync();
+        stamp(5);
+    }
+
+    if (lane == 0) {
+        double *st = g.state + (size_t)gi * g.state_ld;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) st[i] = carry[i];
+        g.fval[gi] = ylast;
+        g.init[gi] = 0;
+        if (kStamp) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.aux) + (size_t)gi * 8;
+            for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* Generic IIR (na != nb, or order above the unrolled kernels): one thread   */
 /* per channel straight out of global memory, reference order, bit-exact.     */
 /* Compatibility path for unusual shapes; not a performance kernel.           */
@@ -648,13 +989,39 @@ static hipError_t launch_seq_n(const GroupView &g, const BlockIO &io, hipStream_
     return hipGetLastError();
 }
 
+/* orders 9..16: the MFMA variant unless DSP_AMD_SCAN16=0 (A/B switch, read once) */
+static bool scan16_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("DSP_AMD_SCAN16");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int N>
 static hipError_t launch_scan_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
-    if (N == 8 && g.unit_a0 && g.aux) {          /* diagnostic build with phase stamps */
-        hipLaunchKernelGGL((iir_scan_kernel<8, kScanT, true, true>), dim3(g.count), dim3(kWave),
-                           Tile<kScanT>::kBytes, s, g, io);
-        return hipGetLastError();
+    if constexpr (N > 8 && kScanT == 64) {
+        if (scan16_enabled()) {
+            if (N == 16 && g.unit_a0 && g.aux)       /* diagnostic build with phase stamps */
+                hipLaunchKernelGGL((iir_scan16_kernel<16, kScanT, true, true>), dim3(g.count), dim3(kWave),
+                                   Tile<kScanT>::kBytes, s, g, io);
+            else if (g.unit_a0)
+                hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
+                                   Tile<kScanT>::kBytes, s, g, io);
+            else
+                hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, false>), dim3(g.count), dim3(kWave),
+                                   Tile<kScanT>::kBytes, s, g, io);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (N == 8 || N == 16) {
+        if (g.unit_a0 && g.aux) {                /* diagnostic build with phase stamps */
+            hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, true, true>), dim3(g.count), dim3(kWave),
+                               Tile<kScanT>::kBytes, s, g, io);
+            return hipGetLastError();
+        }
     }
     if (g.unit_a0)
         hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
