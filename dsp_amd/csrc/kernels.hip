@@ -540,8 +540,9 @@ template <int D>
 __device__ __forceinline__ double row_shift(double cur, double prev)
 {
     static_assert(D >= 1 && D <= 15, "row shift inside a 16-lane group");
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(prev), 0x120 + D, 0xf, 0xf, false);   /* row_ror:D */
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(prev), 0x120 + D, 0xf, 0xf, false);
+    const int plo = __double2loint(prev), phi = __double2hiint(prev);
+    int lo = __builtin_amdgcn_update_dpp(plo, plo, 0x120 + D, 0xf, 0xf, false);                  /* row_ror:D */
+    int hi = __builtin_amdgcn_update_dpp(phi, phi, 0x120 + D, 0xf, 0xf, false);
     lo = __builtin_amdgcn_update_dpp(lo, __double2loint(cur), 0x110 + D, 0xf, 0xf, false);       /* row_shr:D */
     hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(cur), 0x110 + D, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
@@ -577,6 +578,21 @@ __device__ __forceinline__ void scan16_level(d4 (&acc)[4], const double (&Mr)[4]
         for (int rb = 0; rb < 4; ++rb)
             acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mr[ks], u[rb][ks], acc[rb], 0, 0, 0);
     }
+}
+
+
+/* levels 0..NL-1 as one straight-line block, so that the shifts of a level overlap the MFMA tail of the
+ * level before it (a 16-row block only waits for itself and the block in front of it) */
+template <int NL>
+__device__ __forceinline__ void scan16_combine(d4 (&acc)[4], const double (&Mr)[kScanLevels][4],
+                                               const double (&cvirt)[4])
+{
+    if constexpr (NL > 0) scan16_level<0>(acc, Mr[0], cvirt);
+    if constexpr (NL > 1) scan16_level<1>(acc, Mr[1], cvirt);
+    if constexpr (NL > 2) scan16_level<2>(acc, Mr[2], cvirt);
+    if constexpr (NL > 3) scan16_level<3>(acc, Mr[3], cvirt);
+    if constexpr (NL > 4) scan16_level<4>(acc, Mr[4], cvirt);
+    if constexpr (NL > 5) scan16_level<5>(acc, Mr[5], cvirt);
 }
 
 template <int N, int T, bool kUnitA0, bool kStamp = false>
@@ -721,12 +737,15 @@ iir_scan16_kernel(GroupView g, BlockIO io)
             stamp(2);
 
             /* ---- prefix combine over the rows ---- */
-            if (nlev > 0) scan16_level<0>(acc, Mr[0], cvirt);
-            if (nlev > 1) scan16_level<1>(acc, Mr[1], cvirt);
-            if (nlev > 2) scan16_level<2>(acc, Mr[2], cvirt);
-            if (nlev > 3) scan16_level<3>(acc, Mr[3], cvirt);
-            if (nlev > 4) scan16_level<4>(acc, Mr[4], cvirt);
-            if (nlev > 5) scan16_level<5>(acc, Mr[5], cvirt);
+            switch (nlev) {
+                case 0: break;
+                case 1: scan16_combine<1>(acc, Mr, cvirt); break;
+                case 2: scan16_combine<2>(acc, Mr, cvirt); break;
+                case 3: scan16_combine<3>(acc, Mr, cvirt); break;
+                case 4: scan16_combine<4>(acc, Mr, cvirt); break;
+                case 5: scan16_combine<5>(acc, Mr, cvirt); break;
+                default: scan16_combine<6>(acc, Mr, cvirt); break;
+            }
 
             /* end state after row j, row per lane */
             double v[16];
