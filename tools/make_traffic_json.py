@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r1_traffic.json and profiles/r1_fir512_traffic.json from the tools/prof.sh summaries
-(profiles/r1_config2_rocprofv3_summary.txt, profiles/r1_config3_rocprofv3_summary.txt)."""
+(profiles/r1_config{2,3,5}_rocprofv3_summary.txt)."""
 import json
 import os
 import re
@@ -61,7 +61,24 @@ def main():
                "mfma_pipe_utilisation_steady_kernel":
                    steady["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * steady["GRBM_GUI_ACTIVE"] / 8)},
               open(os.path.join(ROOT, "profiles", "r1_fir512_traffic.json"), "w"), indent=1)
-    for n in ("r1_traffic.json", "r1_fir512_traffic.json"):
+    s5 = sections(os.path.join(ROOT, "profiles", "r1_config5_rocprofv3_summary.txt"))
+    f5 = pick(s5["pmc_fetch"], "iir_scan16_kernel")[0]["FETCH_SIZE"]
+    w5 = pick(s5["pmc_write"], "iir_scan16_kernel")[0]["WRITE_SIZE"]
+    m5 = pick(s5["pmc_mfma"], "iir_scan16_kernel")[0]
+    hbm5 = int(f5 * 1024 * 2 + w5 * 1024)
+    alg5 = (1 << 29) * 16
+    json.dump({"kernel": "dsp::iir_scan16_kernel<16, 64, true, false> (one of the two launches of a config-5 step: "
+                         "2^29 samples as 2048 sub-chunks)",
+               "source": "profiles/r1_config5_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
+                         "bench.py --workload stream16 --no-cpu)",
+               "FETCH_SIZE_KiB_per_launch": f5, "WRITE_SIZE_KiB_per_launch": w5, "correction": CORR,
+               "hbm_bytes_per_launch": hbm5, "algorithmic_bytes_per_launch": alg5,
+               "traffic_over_algorithmic": hbm5 / alg5,
+               "mfma_busy_cycles": m5["SQ_VALU_MFMA_BUSY_CYCLES"],
+               "grbm_gui_active_sum_over_8_xcd": m5["GRBM_GUI_ACTIVE"],
+               "mfma_pipe_utilisation": m5["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m5["GRBM_GUI_ACTIVE"] / 8)},
+              open(os.path.join(ROOT, "profiles", "r1_config5_traffic.json"), "w"), indent=1)
+    for n in ("r1_traffic.json", "r1_fir512_traffic.json", "r1_config5_traffic.json"):
         print(n, json.load(open(os.path.join(ROOT, "profiles", n)))["traffic_over_algorithmic"])
 
 

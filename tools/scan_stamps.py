@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import sys
 os.environ["DSP_AMD_SCAN_STAMPS"] = "1"
-os.environ["DSP_AMD_SCAN_VARIANT"] = "scan"
+os.environ["DSP_AMD_SCAN_VARIANT"] = "2"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
