@@ -150,6 +150,27 @@ def test_scan_mixed_orders_noncontiguous_groups(G):
     assert np.all(util.rel_to_peak(yg, yo) <= TOL_SCAN)
 
 
+@pytest.mark.parametrize("order,band", [(9, None), (10, (0.2, 0.5)), (11, None), (12, (0.3, 0.7)), (13, None),
+                                        (14, (0.25, 0.6)), (15, None), (16, (0.2, 0.6))])
+def test_matrix_core_scan_orders_9_to_16(G, order, band):
+    """Orders 9..16 run on the MFMA scan kernel with the states above N as zero padding of its 16-wide tiles:
+    every order, full segments (the MFMA path), ragged and seeded ones (the general path) and the carry between them."""
+    from dsp_amd import bank as gbank, dsp
+    if band is None:
+        f = dsp.butterworth(order, 0.0, 0.3 + 0.01 * order)               # low-pass of that order
+    else:
+        f = dsp.butterworth(order // 2, band[0], band[1])                 # band-pass: twice the prototype order
+    b, a = np.array(f.b()), np.array(f.a())
+    assert len(a) - 1 == order
+    designs = [gbank.iir_design(b, a)]
+    blocks = [64 * 64 * 2 + 5, 64 * 64, 100, 64 * 64 * 3]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, [0] * 5, blocks, gbank.MODE_SCAN, seed=40 + order)
+    yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+    err = util.rel_to_peak(yg, yo)
+    assert np.all(err <= TOL_SCAN), (order, err.max())
+    G.assert_state_equal(gb, ob, exact=False, tol=1e-12)
+
+
 def test_unaligned_pointers_and_inplace(G):
     """Odd leading dimension / 8-byte-aligned base take the scalar access path; in == out allowed."""
     torch = G.torch_mod()
