@@ -45,7 +45,27 @@ constexpr int kPLevels = 6;                 /* log2(64) */
 
 }  // namespace
 
-template <int N, bool kUnitA0>
+/* kWhole: the launch consists of full, 16-byte aligned segments only (n a multiple of 2048).  A separate
+ * instantiation, not a run-time branch: with the guarded ragged loads in the same kernel, hipcc's waitcnt
+ * pass has to assume they may be in flight wherever their registers are reused, and puts vmcnt waits behind
+ * the prefetch that make the front wave wait for nearly all of it (13 us into a launch instead of ~6). */
+/* Rotating issue priority.  The four workgroups that share a CU are otherwise arbitrated oldest-first, and the
+ * one that arrived first finishes a 64K-sample block 10 % ahead of the other three, which then run the tail of
+ * the launch on a half-empty memory system.  Each workgroup takes priority (slot + step) mod 4, slot = its
+ * arrival order on the CU as far as the dispatch order tells (blockIdx / 256). */
+__device__ __forceinline__ void rotate_priority(int k)
+{
+#ifndef EXP_NO_PRIO
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
+}
+
+template <int N, bool kUnitA0, bool kWhole>
 __global__ void __launch_bounds__(2 * kWave, 2)
 iir_pipe_kernel(GroupView g, BlockIO io)
 {
@@ -58,6 +78,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     const int lane = tid & 63;
     const bool front = tid < kWave;
     const int gi = blockIdx.x;
+    const int prio_slot = (int)(blockIdx.x >> 8);
     const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
     const int dsn = as_const(g.design)[gi];
     int nlev = as_const(g.levels2)[dsn];
@@ -78,7 +99,9 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     const int nseg = (int)((n + kPSeg - 1) / kPSeg);
     const double *src = io.in + (size_t)chan * io.ld_in;
     double *dst = io.out + (size_t)chan * io.ld_out;
-    const bool seed_stream = g.init[gi] != 0;
+    /* wave-uniform words of this launch's inputs come through scalar loads: a vector load issued next to the
+     * segment prefetch below would make its first use wait for the whole prefetch (vmcnt counts in order) */
+    const bool seed_stream = as_const(g.init)[gi] != 0;
 
     /* The front wave's first two segments are requested before anything else: the table loads below
      * then run under the cold-start HBM latency instead of in front of it. */
@@ -89,7 +112,17 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         if (base >= n) return;
         const size_t left = n - base;
         const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
-        if (seg_len == kPSeg && io.aligned16) {
+        /* Because a fetch may issue nothing (past the end), hipcc's waitcnt pass assumes at every tile write
+         * that the youngest 16 loads in flight are the ones it needs, i.e. it waits for BOTH prefetched
+         * segments: an effective prefetch distance of one segment.  Measured, that is the better setting:
+         * with the full distance of two (unconditional fetches) the workgroups that the CU favours run
+         * further ahead, the spread of finish times grows from 180-231 to 148-240 us and a 64K block takes
+         * 0.246 instead of 0.240 ms. */
+        if constexpr (kWhole) {
+#pragma unroll
+            for (int i = 0; i < kPPieces; ++i)
+                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+        } else if (seg_len == kPSeg && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < kPPieces; ++i)
                 pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
@@ -108,16 +141,23 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     if (front) {
         fetch(0, pre0);
         fetch(1, pre1);
-        /* Warm the scalar cache: the front wave reads its two tables -- the zero-state response G and the
-         * prefix matrices A^(32 2^k) -- through scalar loads, one 64-byte line after the other as its loops
-         * advance; cold, every line is a separate trip to L2 (~18 us per launch for a 2 KB table).  Touch
-         * all lines now, back to back. */
+    } else {
+        /* The back wave, idle until segment 0 is published, warms the scalar cache of the CU for the front
+         * wave: the front reads its two tables -- the zero-state response G and the prefix matrices
+         * A^(32 2^k) -- through scalar loads, a few 64-byte lines per batch; cold, every batch is a trip to
+         * L2 and, in a full launch, to HBM behind the prefetch of a thousand workgroups.  Touched here, the
+         * lines are requested while that prefetch is still being issued.  All kPLevels matrices (the table
+         * holds kScan2Levels >= kPLevels), whatever nlev is: a loop with a run-time bound would wait for
+         * every line separately. */
         cint_p gw = (cint_p)(uintptr_t)(g.pows + as_const(g.gtab_off)[dsn]);
         int touched = 0;
 #pragma unroll
         for (int l = 0; l < ((PT + 1) * N * 8 + 63) / 64; ++l) touched |= gw[l * 16];
+        asm volatile("" ::"s"(touched));
         cint_p mw = (cint_p)(uintptr_t)(g.pows + as_const(g.pow2_off)[dsn]);
-        for (int l = 0; l < (nlev * N * N * 8 + 63) / 64; ++l) touched |= mw[l * 16];
+        touched = 0;
+#pragma unroll
+        for (int l = 0; l < (kPLevels * N * N * 8 + 63) / 64; ++l) touched |= mw[l * 16];
         asm volatile("" ::"s"(touched));
     }
     if (tid < N) pbuf[tid] = 0.0;                           /* row 0 never receives a prefix */
@@ -140,7 +180,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             a[i] = cf[N + 1 + i];
         }
     };
-    const double tail0 = g.state[(size_t)gi * g.state_ld + N];   /* s[N]: read, never written */
+    const double tail0 = as_const(g.state)[(size_t)gi * g.state_ld + N];   /* s[N]: read, never written */
 
     if (front) {
         /* =============================== FRONT =============================== */
@@ -148,6 +188,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         cdouble_p ptab = as_const(g.pows) + as_const(g.pow2_off)[dsn];      /* [level][i][j], row-major */
         auto front_step = [&](int it, d2(&pre)[kPPieces]) {
             char *tile = (it & 1) ? tile1 : tile0;
+            rotate_priority(prio_slot + it);
             if (it == 0) stamp(1);                            /* set-up done */
             if (it == 8) stamp(11);
             lds_barrier();                                    /* barrier 0 */
@@ -279,26 +320,30 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         }
 
         stamp(9);
-        for (int it = 0; it <= nseg; ++it) {
+        /* step 0 belongs to the front wave alone; its two barriers come before anything that needs the
+         * tables loaded above, so that the front is not held at its first barrier until they have arrived */
+        lds_barrier();
+        lds_barrier();
+        for (int it = 1; it <= nseg; ++it) {
             const int seg = it - 1;
             char *tile = (seg & 1) ? tile1 : tile0;
+            rotate_priority(prio_slot + it);
             lds_barrier();                                    /* barrier 0 */
             double s[N + 1];
-            if (seg >= 0) {
+            {
                 const double *slot = pbuf + lane * N;
 #pragma unroll
                 for (int i = 0; i < N; ++i) s[i] = slot[i];
             }
             lds_barrier();                                    /* barrier 1 */
-            if (seg < 0) continue;
             if (seg == 0) stamp(3);                           /* back starts segment 0 */
             if (seg == 8) stamp(15);
 
             const size_t base = (size_t)seg * kPSeg;
             const size_t left = n - base;
-            const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
+            const int seg_len = kWhole ? kPSeg : (left < (size_t)kPSeg ? (int)left : kPSeg);
             const bool seeded = seed_stream && seg == 0;
-            const bool fast = seg_len == kPSeg && !seeded;
+            const bool fast = (kWhole || seg_len == kPSeg) && !seeded;
 
             /* s_j = P_j + A^(32 j) carry  (row 0: P = 0, A^0 = I) */
             if (!seeded) {
@@ -315,16 +360,22 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             char *row = tile + lane * (PT * 8);
             double y = ylast;
             if (fast) {
-                /* the whole row in one burst of LDS reads, then arithmetic only */
-                d2 xr[PT / 2];
+                /* the row in two bursts of LDS reads (a whole row at once would push the lane's propagator
+                 * matrix out of the register file), then arithmetic only */
+                constexpr int kBurst = PT / 4;
 #pragma unroll
-                for (int q = 0; q < PT / 2; ++q) xr[q] = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+                for (int h = 0; h < PT / 2; h += kBurst) {
+                    d2 xr[kBurst];
 #pragma unroll
-                for (int q = 0; q < PT / 2; ++q) {
-                    d2 xv = xr[q];
-                    xv.x = iir_step_fused<N, kUnitA0>(xv.x, s, b, a);
-                    xv.y = y = iir_step_fused<N, kUnitA0>(xv.y, s, b, a);
-                    *reinterpret_cast<d2 *>(row + ((q << 4) ^ rx)) = xv;
+                    for (int q = 0; q < kBurst; ++q)
+                        xr[q] = *reinterpret_cast<const d2 *>(row + (((h + q) << 4) ^ rx));
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q) {
+                        d2 xv = xr[q];
+                        xv.x = iir_step_fused<N, kUnitA0>(xv.x, s, b, a);
+                        xv.y = y = iir_step_fused<N, kUnitA0>(xv.y, s, b, a);
+                        *reinterpret_cast<d2 *>(row + (((h + q) << 4) ^ rx)) = xv;
+                    }
                 }
             } else {
                 int cnt = seg_len - lane * PT;
@@ -350,7 +401,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             /* store the segment, coalesced (this wave wrote the whole tile: in-order LDS) */
             if (seg == 0) stamp(10);
             wave_sync();
-            if (seg_len == kPSeg && io.aligned16) {
+            if (kWhole || (seg_len == kPSeg && io.aligned16)) {
 #pragma unroll 8
                 for (int i = 0; i < kPPieces; ++i)
                     *reinterpret_cast<d2 *>(dst + base + 2 * (i * kWave + lane)) =
@@ -381,10 +432,15 @@ template <int N>
 static hipError_t launch_pipe_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
     const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * N;
-    if (g.unit_a0)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+    const bool whole = io.aligned16 && io.n % kPSeg == 0;
+    if (g.unit_a0 && whole)
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+    else if (g.unit_a0)
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+    else if (whole)
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
     else
-        hipLaunchKernelGGL((iir_pipe_kernel<N, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
     return hipGetLastError();
 }
 
