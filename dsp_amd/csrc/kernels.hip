@@ -950,7 +950,7 @@ __global__ void synth_kernel(double *dst, size_t ld, size_t nch, size_t n, uint6
 /* Diagnostic: the scan kernels' memory access pattern with no arithmetic -- one workgroup per
  * channel walks its row in `seg`-sample pieces, two pieces of loads in flight, coalesced 16-byte
  * loads and stores.  Gives the HBM ceiling OF THIS PATTERN to read roofline fractions against. */
-template <int kThreads>
+template <int kThreads, int kNT = 0>
 __global__ void __launch_bounds__(kThreads)
 copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, size_t n, int seg)
 {
@@ -962,13 +962,20 @@ copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, siz
         if (base >= n) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (i < per) buf[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kThreads + threadIdx.x));
+            if (i < per) {
+                const d2 *p = reinterpret_cast<const d2 *>(src + base + 2 * (i * kThreads + threadIdx.x));
+                buf[i] = (kNT & 1) ? __builtin_nontemporal_load(p) : *p;
+            }
     };
     auto store = [&](size_t base, d2(&buf)[16]) {
         if (base >= n) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (i < per) *reinterpret_cast<d2 *>(dst + base + 2 * (i * kThreads + threadIdx.x)) = buf[i];
+            if (i < per) {
+                d2 *p = reinterpret_cast<d2 *>(dst + base + 2 * (i * kThreads + threadIdx.x));
+                if (kNT & 2) __builtin_nontemporal_store(buf[i], p);
+                else *p = buf[i];
+            }
     };
     load(0, buf0);
     load(seg, buf1);
@@ -983,7 +990,16 @@ copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, siz
 hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
                             size_t n, int threads, int seg, hipStream_t s)
 {
-    if (threads == 64)
+    /* diagnostics: DSP_COPY_NT = 1 nontemporal loads, 2 nontemporal stores, 3 both (256-thread variant) */
+    const char *nt = std::getenv("DSP_COPY_NT");
+    const int ntm = nt ? std::atoi(nt) : 0;
+    if (threads == 256 && ntm == 1)
+        hipLaunchKernelGGL((copy_rows_kernel<256, 1>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+    else if (threads == 256 && ntm == 2)
+        hipLaunchKernelGGL((copy_rows_kernel<256, 2>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+    else if (threads == 256 && ntm == 3)
+        hipLaunchKernelGGL((copy_rows_kernel<256, 3>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+    else if (threads == 64)
         hipLaunchKernelGGL(copy_rows_kernel<64>, dim3((unsigned)nch), dim3(64), 0, s, out, ld_out, in, ld_in, n, seg);
     else if (threads == 128)
         hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg);

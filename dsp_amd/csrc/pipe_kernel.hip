@@ -121,11 +121,11 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         if constexpr (kWhole) {
 #pragma unroll
             for (int i = 0; i < kPPieces; ++i)
-                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
         } else if (seg_len == kPSeg && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < kPPieces; ++i)
-                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
         } else {
 #pragma unroll
             for (int i = 0; i < kPPieces; ++i) {
@@ -404,8 +404,8 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             if (kWhole || (seg_len == kPSeg && io.aligned16)) {
 #pragma unroll 8
                 for (int i = 0; i < kPPieces; ++i)
-                    *reinterpret_cast<d2 *>(dst + base + 2 * (i * kWave + lane)) =
-                        *reinterpret_cast<const d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]);
+                    stream_store(reinterpret_cast<d2 *>(dst + base + 2 * (i * kWave + lane)),
+                                 *reinterpret_cast<const d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]));
             } else {
 #pragma unroll 4
                 for (int i = 0; i < kPPieces; ++i) {
