@@ -974,8 +974,12 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
          * fast as the scan kernels (tools/seq_sweep.py, order 8: 4.3 vs 4.7 TB/s at 65 536 x 16K, 4.9 vs
          * 3.9 TB/s at 262 144 x 4K; order 16: 3.6 vs 2.8 TB/s; short blocks: 4.5 vs 0.3 TB/s at 2^20 x 256);
          * below that (3.3 vs 4.7 TB/s at 32 768 channels) the time-parallel kernels win.  Orders <= 8 switch
-         * one octave later: at exactly 65 536 channels x 64K the pipelined kernel still leads (4.6 vs 3.7 TB/s). */
-        const size_t seq_from = g.order <= kScan2MaxOrder ? 2 * kAutoSeqMinChannels : kAutoSeqMinChannels;
+         * one octave later: at exactly 65 536 channels x 64K the pipelined kernel still leads (4.6 vs 3.7 TB/s).
+         * Orders 9..16: the matrix-core scan kernel leads at every width once a call holds a full 4096-sample
+         * segment (4.6 vs 3.7 TB/s at 65 536 x 16K, 4.1 vs 3.7 at 262 144 x 4K); shorter calls of wide banks
+         * stay on the lane-per-channel kernel. */
+        const size_t seq_from = g.order <= kScan2MaxOrder ? 2 * kAutoSeqMinChannels
+                                : (n >= (size_t)kWave * kScanT ? (size_t)-1 : kAutoSeqMinChannels);
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
                    (bank->mode == RTFB_MODE_AUTO && (!g.scan_safe || g.chans.size() >= seq_from));
         if (!seq && !iir_scan_supported(g.order)) seq = true;

@@ -93,7 +93,7 @@ iir_seq_kernel(GroupView g, BlockIO io)
 #pragma unroll
         for (int i = 0; i < TG::kLoads; ++i) {
             const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
-            pre[i] = *reinterpret_cast<const d2 *>(io.in + (size_t)cr * io.ld_in + t0 + 2 * st_q);
+            pre[i] = stream_load(reinterpret_cast<const d2 *>(io.in + (size_t)cr * io.ld_in + t0 + 2 * st_q));
         }
     };
     if (wide && n >= (size_t)T) fetch(0);
@@ -123,8 +123,8 @@ iir_seq_kernel(GroupView g, BlockIO io)
 #pragma unroll
             for (int i = 0; i < TG::kLoads; ++i) {
                 const int cr = __shfl(chan, i * kRowsPerPass + st_r, kWave);
-                *reinterpret_cast<d2 *>(io.out + (size_t)cr * io.ld_out + t0 + 2 * st_q) =
-                    *reinterpret_cast<const d2 *>(smem + (i * kRowsPerPass + st_r) * TG::kRowBytes + st_q * 16);
+                stream_store(reinterpret_cast<d2 *>(io.out + (size_t)cr * io.ld_out + t0 + 2 * st_q),
+                             *reinterpret_cast<const d2 *>(smem + (i * kRowsPerPass + st_r) * TG::kRowBytes + st_q * 16));
             }
             wave_sync();
             continue;
@@ -394,7 +394,7 @@ iir_scan_kernel(GroupView g, BlockIO io)
         if (seg_len == kSeg && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < TG::kLoads; ++i)
-                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
         } else {
 #pragma unroll
             for (int i = 0; i < TG::kLoads; ++i) {
@@ -448,8 +448,8 @@ iir_scan_kernel(GroupView g, BlockIO io)
 #pragma unroll 8
             for (int i = 0; i < TG::kLoads; ++i) {
                 const int p = i * kWave + lane;
-                *reinterpret_cast<d2 *>(dst + base + 2 * p) = *reinterpret_cast<const d2 *>(
-                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+                stream_store(reinterpret_cast<d2 *>(dst + base + 2 * p), *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16));
             }
         } else {
 #pragma unroll 4
@@ -663,7 +663,7 @@ iir_scan16_kernel(GroupView g, BlockIO io)
         if (seg_len == kSeg && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < TG::kLoads; ++i)
-                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
         } else {
 #pragma unroll
             for (int i = 0; i < TG::kLoads; ++i) {
@@ -807,8 +807,8 @@ iir_scan16_kernel(GroupView g, BlockIO io)
 #pragma unroll 8
             for (int i = 0; i < TG::kLoads; ++i) {
                 const int p = i * kWave + lane;
-                *reinterpret_cast<d2 *>(dst + base + 2 * p) = *reinterpret_cast<const d2 *>(
-                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
+                stream_store(reinterpret_cast<d2 *>(dst + base + 2 * p), *reinterpret_cast<const d2 *>(
+                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16));
             }
         } else {
 #pragma unroll 4

@@ -122,7 +122,7 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
         if (seg_len == kSeg2 && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < kPiecesPerThread; ++i)
-                pre[i] = *reinterpret_cast<const d2 *>(src + base + 2 * (i * kRows + tid));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kRows + tid)));
         } else {
 #pragma unroll
             for (int i = 0; i < kPiecesPerThread; ++i) {
@@ -327,8 +327,8 @@ iir_scan2_kernel(GroupView g, BlockIO io, int xbuf_rows)
         if (seg_len == kSeg2 && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < kPiecesPerThread; ++i)
-                *reinterpret_cast<d2 *>(dst + base + 2 * (i * kRows + tid)) =
-                    *reinterpret_cast<const d2 *>(tile + i * (8 * T2 * 8) + ((i & 1) ? st_odd : st_even));
+                stream_store(reinterpret_cast<d2 *>(dst + base + 2 * (i * kRows + tid)),
+                             *reinterpret_cast<const d2 *>(tile + i * (8 * T2 * 8) + ((i & 1) ? st_odd : st_even)));
         } else {
 #pragma unroll 4
             for (int i = 0; i < kPiecesPerThread; ++i) {

@@ -54,9 +54,9 @@ typedef struct RTFilterDesign {
 
 /* Kernel choice.
  * AUTO        fastest kernels that meet the 1e-12 relative-to-peak bar: IIR channels on the
- *             time-parallel scan kernels when their group has fewer than 131072 channels (65536 for
- *             orders above 8: too few to fill the GPU with one lane per channel) and the design passes
- *             the conditioning probe,
+ *             time-parallel scan kernels when their group has fewer than 131072 channels (orders above
+ *             8: at any width once a call brings >= 4096 samples, else below 65536 channels) and the
+ *             design passes the conditioning probe,
  *             else on the bit-exact sequential kernel; FIR channels of >= 17 taps on the
  *             Toeplitz-tile FP64 MFMA kernel (else bit-exact).
  * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
