@@ -560,6 +560,9 @@ struct MfmaItem {
 };
 
 constexpr int kMfmaPre = 19;    /* input doubles per thread fetched one item ahead: covers K <= 753 */
+constexpr int kMfmaPre2 = 10;   /* the same as 16-byte pairs when the rows allow it (x0 is then 16-byte aligned:
+                                   seg_base and hist are multiples of 16) */
+constexpr int kMfmaPreElems = 2 * kMfmaPre2 * kMfmaWaves * kWave;   /* 5120 >= 19 * 256: LDS is sized for it */
 
 __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg)
 {
@@ -623,9 +626,21 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
     int seg = (int)(idx - (long long)gi * nseg);
 
     MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg);
+    /* emax is odd here (hist + 4096 - 1 when the block ends with the item, else hist + 4096 + 15), so a pair
+     * clamped to emax >> 1 never reaches past it; clamped positions only ever meet zero taps */
     double xr[kMfmaPre];
+    d2 xr2[kMfmaPre2];
+    auto prefetch = [&](const MfmaItem &it) {
+        if constexpr (kAligned16) {
 #pragma unroll
-    for (int k = 0; k < kMfmaPre; ++k) xr[k] = cur.x0[min(tid + kThreads * k, cur.emax)];
+            for (int k = 0; k < kMfmaPre2; ++k)
+                xr2[k] = *reinterpret_cast<const d2 *>(it.x0 + 2 * min(tid + kThreads * k, it.emax >> 1));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMfmaPre; ++k) xr[k] = it.x0[min(tid + kThreads * k, it.emax)];
+        }
+    };
+    prefetch(cur);
     int staged_dsn = -1;
     d4 acc[kMfmaTiles];
     double *pending = nullptr;                                  /* where the previous item's results go */
@@ -638,9 +653,15 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
 
         lds_barrier();                                        /* the previous item's operand reads are over */
         /* (first, so that the wait is for the prefetch only: the previous item's stores are younger) */
+        if constexpr (kAligned16) {
 #pragma unroll
-        for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
-        for (int e = tid + kThreads * kMfmaPre; e < total; e += kThreads)       /* very long filters */
+            for (int k = 0; k < kMfmaPre2; ++k)            /* elements 2p, 2p+1 share a 16-group: one 16-byte write */
+                *reinterpret_cast<d2 *>(xs + xpos(2 * (tid + kThreads * k))) = xr2[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
+        }
+        for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
             xs[xpos(e)] = cur.x0[min(e, cur.emax)];
         if (cur.dsn != staged_dsn) {
             for (int e = tid; e < nb_pad; e += kThreads) {
@@ -668,8 +689,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
                 const long long last = (long long)io.n - 1 - ((long long)(steady_lo + seg) * kMfmaSeg - cur.hist);
                 nxt.emax = last < cur.hist + kMfmaSeg + 15 ? (int)last : cur.hist + kMfmaSeg + 15;
             }
-#pragma unroll
-            for (int k = 0; k < kMfmaPre; ++k) xr[k] = nxt.x0[min(tid + kThreads * k, nxt.emax)];
+            prefetch(nxt);
         }
 
 #pragma unroll
@@ -948,7 +968,7 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         }
         const int hist = 16 * (mfma_steps16(g.kmax) - 1);
         int xtotal = hist + kMfmaSeg + 16;
-        if (xtotal < kMfmaPre * kMfmaWaves * kWave) xtotal = kMfmaPre * kMfmaWaves * kWave;
+        if (xtotal < kMfmaPreElems) xtotal = kMfmaPreElems;
         const size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
         const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);       /* segments per channel */
         /* steady segments: first output has more than kmax samples behind it (and lies past any
