@@ -409,6 +409,10 @@ constexpr int kMfmaSeg = kMfmaWaves * kMfmaTiles * 256;          /* outputs per 
 constexpr int kPitch = 18;                                       /* LDS doubles per 16 inputs */
 __host__ __device__ constexpr int mfma_steps16(int K) { return (K - 1 + 15) / 16 + 1; }   /* outer steps */
 __device__ __forceinline__ int xpos(int e) { return e + 2 * (e >> 4); }
+constexpr int kMfmaPre = 19;    /* input doubles per thread fetched one item ahead: covers K <= 753 */
+constexpr int kMfmaPre2 = 10;   /* the same as 16-byte pairs when the rows allow it (x0 is then 16-byte aligned:
+                                   seg_base and hist are multiples of 16) */
+constexpr int kMfmaPreElems = 2 * kMfmaPre2 * kMfmaWaves * kWave;   /* 5120 >= 19 * 256: LDS is sized for it */
 
 struct MfmaOperands {
     double a[4];
@@ -484,10 +488,27 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
         const int k = e - 16;
         bp[e] = (k >= 0 && k < K) ? b[k] : 0.0;
     }
-    /* samples before t0 were consumed by stable_init (or do not exist): they feed nothing */
-    for (int e = tid; e < total; e += kMfmaWaves * kWave) {
-        const long long idx = seg_base - hist + e;
-        xs[xpos(e)] = (idx >= t0 && idx < n) ? x[idx] : 0.0;
+    /* samples before t0 were consumed by stable_init (or do not exist): they feed nothing.  The loads are
+     * unconditional on a clamped index and the guard is a select afterwards: guarded loads compile to a branch
+     * each and wait one by one (this kernel ran at half the bandwidth of the steady one). */
+    {
+        constexpr int kThreads = kMfmaWaves * kWave;
+        double xr[kMfmaPre];
+#pragma unroll
+        for (int k = 0; k < kMfmaPre; ++k) {
+            long long idx = seg_base - hist + tid + kThreads * k;
+            idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
+            xr[k] = x[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < kMfmaPre; ++k) {                /* LDS holds kMfmaPreElems >= 19 * 256 inputs */
+            const long long idx = seg_base - hist + tid + kThreads * k;
+            xs[xpos(tid + kThreads * k)] = (idx >= t0 && idx < n) ? xr[k] : 0.0;
+        }
+        for (int e = tid + kThreads * kMfmaPre; e < total; e += kThreads) {     /* very long filters */
+            const long long idx = seg_base - hist + e;
+            xs[xpos(e)] = (idx >= t0 && idx < n) ? x[idx] : 0.0;
+        }
     }
     __syncthreads();
 
@@ -559,10 +580,6 @@ struct MfmaItem {
     int K, dsn, hist, steps;
 };
 
-constexpr int kMfmaPre = 19;    /* input doubles per thread fetched one item ahead: covers K <= 753 */
-constexpr int kMfmaPre2 = 10;   /* the same as 16-byte pairs when the rows allow it (x0 is then 16-byte aligned:
-                                   seg_base and hist are multiples of 16) */
-constexpr int kMfmaPreElems = 2 * kMfmaPre2 * kMfmaWaves * kWave;   /* 5120 >= 19 * 256: LDS is sized for it */
 
 __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg)
 {
