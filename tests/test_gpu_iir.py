@@ -171,6 +171,26 @@ def test_matrix_core_scan_orders_9_to_16(G, order, band):
     G.assert_state_equal(gb, ob, exact=False, tol=1e-12)
 
 
+def test_matrix_core_scan_a0_not_one_unaligned_inplace(G):
+    """Order-12 design with a0 = 2 (every coefficient doubled: the same filter), odd row pitch and an 8-byte aligned
+    base (scalar access path), in place."""
+    torch = G.torch_mod()
+    from dsp_amd import bank as gbank, dsp
+    from oracle import oracle as orc
+    f = dsp.butterworth(6, 0.3, 0.7)
+    b, a = 2.0 * np.array(f.b()), 2.0 * np.array(f.a())
+    d = gbank.iir_design(b, a)
+    nch, n, ld = 3, 64 * 64 * 2 + 77, 64 * 64 * 2 + 79
+    x = G.make_inputs(23, nch, n)
+    buf = torch.zeros(nch * ld + 1, dtype=torch.float64, device="cuda")
+    view = buf[1:].view(nch, ld)[:, :n]
+    view.copy_(G.to_dev(x))
+    gb = gbank.FilterBank([d], [0] * nch, mode=gbank.MODE_SCAN)
+    gb(view, out=view)
+    yo = orc.Bank([G.to_orc_design(d)], [0] * nch).updaten(x)
+    assert np.all(util.rel_to_peak(view.cpu().numpy(), yo) <= TOL_SCAN)
+
+
 def test_unaligned_pointers_and_inplace(G):
     """Odd leading dimension / 8-byte-aligned base take the scalar access path; in == out allowed."""
     torch = G.torch_mod()
