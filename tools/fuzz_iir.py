@@ -16,7 +16,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst = 0.0
 for c in range(cases):
-    order = int(rng.integers(1, 17))
+    order = int(rng.integers(int(os.environ.get('FUZZ_MIN_ORDER', '1')), 17))
     if order % 2 == 0 and rng.random() < 0.5:
         lo = 0.15 + 0.2 * rng.random()
         f = dsp.butterworth(order // 2, lo, lo + 0.2 + 0.2 * rng.random())
@@ -29,6 +29,8 @@ for c in range(cases):
     blocks = [int(rng.choice([1, 7, 100, 2048, 4096, 4096 + 5, 6144, 8192, 12288, 12288 + 2047, 16384]))
               for _ in range(int(rng.integers(2, 5)))]
     mode = gbank.MODE_SCAN if rng.random() < 0.7 else gbank.MODE_AUTO
+    if os.environ.get('FUZZ_MODE') == 'auto':
+        mode = gbank.MODE_AUTO
     d = gbank.iir_design(b, a)
     ys_g, ys_o, gb, ob = G.run_pair([d], [0] * nch, blocks, mode, seed=100 + c)
     err = float(np.max(util.rel_to_peak(np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1))))
