@@ -553,9 +553,10 @@ def main_stream16(args):
                                      if world == 1 and args.stream_log2 == 30
                                      and measured_traffic("r1_config5_traffic.json") else None),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
-                         "note": "per-GPU bytes of one step (two launches of the scan kernel over 2^29 samples each "
-                                 "plus run-ups and hand-off) over the step's device time on rank 0; traffic = PMC "
-                                 "bytes of the two launches (profiles/r1_config5_traffic.json)",
+                         "note": "per-GPU bytes of one step (the run-up launch over the sub-chunks' tails, the main "
+                                 "launch of the scan kernel over all sub-chunks, state copies) over the step's device "
+                                 "time on rank 0; traffic = PMC bytes of the two launches "
+                                 "(profiles/r1_config5_traffic.json)",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         if world == 1 and not args.no_cpu:

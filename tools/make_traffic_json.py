@@ -66,9 +66,10 @@ def main():
     w5 = pick(s5["pmc_write"], "iir_scan16_kernel")[0]["WRITE_SIZE"]
     m5 = pick(s5["pmc_mfma"], "iir_scan16_kernel")[0]
     hbm5 = int(f5 * 1024 * 2 + w5 * 1024)
-    alg5 = (1 << 29) * 16
-    json.dump({"kernel": "dsp::iir_scan16_kernel<16, 64, true, false> (one of the two launches of a config-5 step: "
-                         "2^29 samples as 2048 sub-chunks)",
+    alg5 = (1 << 29) * 16          # half a step: the means are over two launches
+    json.dump({"kernel": "dsp::iir_scan16_kernel<16, 64, true, false>: mean over the two launches of a config-5 step "
+                         "(run-up over the sub-chunks' 1024-sample tails + main launch over 2^30 samples), so that "
+                         "2 x the per-launch figures = one step",
                "source": "profiles/r1_config5_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
                          "bench.py --workload stream16 --no-cpu)",
                "FETCH_SIZE_KiB_per_launch": f5, "WRITE_SIZE_KiB_per_launch": w5, "correction": CORR,
