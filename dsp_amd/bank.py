@@ -34,6 +34,10 @@ def device_count():
     return dspdll.dsp_device_count()
 
 
+def noalloc_max_doubles():
+    return dspdll.RTFilterBank_noalloc_max_doubles()
+
+
 def _stream_ptr(stream):
     if stream is None:
         try:
@@ -115,6 +119,12 @@ class FilterBank:
     def updaten_ptr(self, out_ptr, ld_out, in_ptr, ld_in, n, stream=None):
         _check(dspdll.RTFilterBank_updaten(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
                                            ld_in, n, _stream_ptr(stream)), "RTFilterBank_updaten")
+
+    def updaten_ptr_noalloc(self, out_ptr, ld_out, in_ptr, ld_in, n, stream=None):
+        """RTFilterBank_updaten_noalloc: the same update without any allocation (in-place FIR calls stage
+        through the library's static device array; RTFB_ESIZE beyond noalloc_max_doubles())."""
+        _check(dspdll.RTFilterBank_updaten_noalloc(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
+                                                   ld_in, n, _stream_ptr(stream)), "RTFilterBank_updaten_noalloc")
 
     def __call__(self, x, out=None, stream=None):
         """x: (nch, n) float64 device tensor with contiguous rows.  Returns the output tensor."""

@@ -149,6 +149,9 @@ _proto("RTFilterBank_destroy", None, [c_void_p])
 _proto("RTFilterBank_channels", c_size_t, [c_void_p])
 _proto("RTFilterBank_set_mode", c_int, [c_void_p, c_int])
 _proto("RTFilterBank_updaten", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
+_proto("RTFilterBank_updaten_noalloc", c_int,
+       [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
+_proto("RTFilterBank_noalloc_max_doubles", c_size_t, [])
 _proto("RTFilterBank_reset", c_int, [c_void_p, c_void_p])
 _proto("RTFilterBank_sync_to_host", c_int, [c_void_p, c_void_p])
 _proto("RTFilterBank_state_ld", c_size_t, [c_void_p])

@@ -27,6 +27,13 @@
 #include "RTFilterStream.h"
 #include "dsp_internal.h"
 
+/* Staging buffer of RTFilterBank_updaten_noalloc (the entry point for callers that cannot allocate: HIP graph
+ * capture, serving loops, harnesses that forbid hipMalloc).  One copy per GPU the library runs on, held until the
+ * process ends.  In host code this name is a stand-in, not a device address: host code uses the pointer that
+ * hipGetSymbolAddress returned for the device (static_scratch_of), never the name. */
+constexpr size_t kStaticScratchDoubles = (size_t)4 << 20;          /* 32 MiB */
+static __device__ __align__(256) double scratch[kStaticScratchDoubles];
+
 namespace {
 
 using namespace dsp;
@@ -78,6 +85,31 @@ int check_device(int device)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RTFB_EDEVICE, std::string("device is ") + prop.gcnArchName +
                                       "; this library carries gfx950 (MI355X) code only");
+    return RTFB_OK;
+}
+
+/* Device address of `scratch` on `device`, looked up once per device with that device current (every GPU holds
+ * its own copy of the array at its own address).  Called at bank creation, never from the update path. */
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double *g_scratch_ptr[kMaxDevices] = {};
+
+int static_scratch_of(int device, double **ptr)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RTFB_EINVAL, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        DeviceScope ds(device);
+        if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return fail_hip(e, "hipGetSymbolAddress(scratch)");
+        }
+        g_scratch_ptr[device] = static_cast<double *>(p);
+    }
+    *ptr = g_scratch_ptr[device];
     return RTFB_OK;
 }
 
@@ -246,6 +278,7 @@ struct RTFilterBank {
             *d_levels1 = nullptr, *d_gtab1_off = nullptr,
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
+    double *d_static_scratch = nullptr;   /* this device's copy of `scratch` (RTFilterBank_updaten_noalloc) */
 };
 
 namespace {
@@ -487,6 +520,10 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     const int device = bk->device;
     DeviceScope ds(device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    {
+        int rc0 = static_scratch_of(device, &bk->d_static_scratch);
+        if (rc0) return rc0;
+    }
 
     /* design tables */
     std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, levels1, gtab1_off, nb, na, kind;
@@ -912,8 +949,8 @@ int RTFilterBank_set_mode(RTFilterBank *bank, int mode)
     return RTFB_OK;
 }
 
-int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
-                         size_t ld_in, size_t n, void *hip_stream)
+static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
+                        size_t ld_in, size_t n, void *hip_stream, bool no_alloc)
 {
     if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten: NULL argument");
     if (n == 0) return RTFB_OK;
@@ -941,7 +978,18 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
             BlockIO fio = io;
             const double *in_end = in + (bank->nch - 1) * ld_in + n;
             const double *out_end = out + (bank->nch - 1) * ld_out + n;
-            if (in < out_end && out < in_end) {
+            if (in < out_end && out < in_end && no_alloc) {
+                /* staging through this GPU's static array: no pool, no hipMalloc */
+                const size_t need = bank->nch * n;
+                if (need > kStaticScratchDoubles)
+                    return fail(RTFB_ESIZE, "RTFilterBank_updaten_noalloc: an in-place call on FIR channels stages "
+                                            "channels x n doubles; the static scratch holds " +
+                                                std::to_string(kStaticScratchDoubles));
+                HIP_TRY(hipMemcpy2DAsync(bank->d_static_scratch, n * sizeof(double), in, ld_in * sizeof(double),
+                                         n * sizeof(double), bank->nch, hipMemcpyDeviceToDevice, s));
+                fio.in = bank->d_static_scratch;
+                fio.ld_in = n;
+            } else if (in < out_end && out < in_end) {
                 const size_t need = bank->nch * n;
                 if (g.scratch_doubles < need) {
                     HIP_TRY(hipStreamSynchronize(s));
@@ -992,6 +1040,20 @@ int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const d
     }
     return RTFB_OK;
 }
+
+int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
+                         size_t ld_in, size_t n, void *hip_stream)
+{
+    return bank_updaten(bank, out, ld_out, in, ld_in, n, hip_stream, false);
+}
+
+int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
+                                 size_t ld_in, size_t n, void *hip_stream)
+{
+    return bank_updaten(bank, out, ld_out, in, ld_in, n, hip_stream, true);
+}
+
+size_t RTFilterBank_noalloc_max_doubles(void) { return kStaticScratchDoubles; }
 
 int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch, size_t n,
                   int threads, int seg, void *hip_stream)

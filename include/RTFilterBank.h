@@ -99,6 +99,20 @@ EXPORT int    RTFilterBank_set_mode(RTFilterBank *bank, int mode);
 EXPORT int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out,
                                 const double *in, size_t ld_in, size_t n, void *hip_stream);
 
+/* RTFilterBank_updaten for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  (No counterpart in the reference.)  Same arguments, same results,
+ * same state carried; this entry point calls no hipMalloc / hipFree / pool routine.  The one place where
+ * RTFilterBank_updaten may allocate -- an in-place call (in and out overlap) on FIR channels, whose kernels read
+ * from a private copy of the input because FIR outputs are produced out of time order -- stages that copy in a
+ * static device array of the library instead: channels x n <= RTFilterBank_noalloc_max_doubles() (4 Mi doubles =
+ * 32 MiB, held by every GPU the library runs on until the process ends), else RTFB_ESIZE.  Every call on a GPU shares that
+ * GPU's array: calls that overlap in time on one GPU (different streams or threads) race on it; calls on one
+ * stream are ordered.  Calls that are not in place, or touch no FIR channel, need no staging and have no size
+ * limit. */
+EXPORT int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out,
+                                        const double *in, size_t ld_in, size_t n, void *hip_stream);
+EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
+
 /* RTFilter_reset on every channel (state untouched, src/RTFilter.c:55-58). */
 EXPORT int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream);
 
