@@ -102,10 +102,11 @@ def cpu_baseline(b, a):
                        % (threads * per_thread, DESIGN, threads, dt))
 
 
-def measured_traffic(name="r1_traffic.json"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes).  None if
-    the profile file is absent; bench.py itself does not run the profiler."""
+def measured_traffic(name="r2_traffic.json"):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes).  A stored constant, not
+    something this run measured (bench.py does not run the profiler): the bench line names the file under
+    `traffic_source`.  None if the profile file is absent."""
     path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as fh:
@@ -134,6 +135,12 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="config 4: all_gather every channel's filtered_value after each block (RCCL)")
     ap.add_argument("--fir-channels", type=int, default=65536)
+    ap.add_argument("--layout", choices=["blocks", "rows"], default="blocks",
+                    help="config 2: how the resident 2^20-sample streams lie in HBM: `rows` = one row of 2^20 samples per "
+                         "channel, `blocks` = 16 block buffers of 1024 x 64K")
+    ap.add_argument("--block-pad", type=int, default=0, help="layout blocks: extra doubles per row")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default run only: skip the compact config-3 and config-5 legs attached under `other_configs`")
     args = ap.parse_args()
     if args.workload == "fir512":
         return main_fir512(args)
@@ -168,10 +175,23 @@ def main():
     else:
         bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
 
-    xbuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
-    ybuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
-    x, y = xbuf[:, :STREAM], ybuf[:, :STREAM]
-    gbank.synth_fill(x, SEED, chan0=rank * CHANNELS, n0=0)
+    if args.layout == "rows":
+        # every channel's 2^20 samples contiguous (row pitch 2^20 + 128 doubles); block j = columns [j*64K, (j+1)*64K)
+        pitch = PITCH
+        xbuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
+        ybuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
+        gbank.synth_fill(xbuf[:, :STREAM], SEED, chan0=rank * CHANNELS, n0=0)
+        xptr = [xbuf.data_ptr() + j * BLOCK * 8 for j in range(NBLOCKS)]
+        yptr = [ybuf.data_ptr() + j * BLOCK * 8 for j in range(NBLOCKS)]
+    else:
+        # the stream as it is streamed: 16 block buffers of 1024 x 64K (each 512 MiB, rows dense), all resident
+        pitch = BLOCK + args.block_pad
+        xbuf = torch.empty((NBLOCKS, CHANNELS, pitch), dtype=torch.float64, device=dev)
+        ybuf = torch.empty((NBLOCKS, CHANNELS, pitch), dtype=torch.float64, device=dev)
+        for j in range(NBLOCKS):
+            gbank.synth_fill(xbuf[j][:, :BLOCK], SEED, chan0=rank * CHANNELS, n0=j * BLOCK)
+        xptr = [xbuf[j].data_ptr() for j in range(NBLOCKS)]
+        yptr = [ybuf[j].data_ptr() for j in range(NBLOCKS)]
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
@@ -183,23 +203,26 @@ def main():
             bank.reset(stream)
         if ev is not None:
             ev[0].record(stream)
-        bank.updaten_ptr(y.data_ptr() + j * BLOCK * 8, PITCH, x.data_ptr() + j * BLOCK * 8, PITCH,
-                         BLOCK, stream)
+        bank.updaten_ptr(yptr[j], pitch, xptr[j], pitch, BLOCK, stream)
         if ev is not None:
             ev[1].record(stream)
         step_no[0] += 1
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
+    # ONE pair of HIP events brackets the timed steps on the launch stream: average launch duration =
+    # (e_end - e_begin) / steps.  (An event pair around every launch puts two marker packets between consecutive
+    # kernels and costs ~6 us of wall time per step; the per-launch pairs are taken in an untimed pass below.)
+    e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e_begin.record(stream)
     for k in range(args.steps):
-        step(events[k])
+        step()
+    e_end.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -209,9 +232,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=_reduce_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kern_avg_s = e_begin.elapsed_time(e_end) / 1e3 / args.steps
 
+    # untimed extra: per-launch event pairs (spread of single launches)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+    for k in range(16):
+        step(events[k])
+    torch.cuda.synchronize()
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in events]
-    kern_avg_s = float(np.mean(kern_ms)) / 1e3
 
     # Streaming-copy ceiling of this device for the same shape (1024 rows x one 64K block, read + write,
     # no arithmetic): what a 16 B/sample kernel could reach at best here.  Untimed extra, rank 0 only.
@@ -224,8 +252,7 @@ def main():
             j = k % NBLOCKS
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            rc = dspdll.dsp_copy_rows(C.c_void_p(y.data_ptr() + j * BLOCK * 8), PITCH,
-                                      C.c_void_p(x.data_ptr() + j * BLOCK * 8), PITCH, CHANNELS, BLOCK,
+            rc = dspdll.dsp_copy_rows(C.c_void_p(yptr[j]), pitch, C.c_void_p(xptr[j]), pitch, CHANNELS, BLOCK,
                                       256, 8192, C.c_void_p(stream.cuda_stream))
             e1.record(stream)
             torch.cuda.synchronize()
@@ -247,24 +274,48 @@ def main():
                                    "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
-                       "row_pitch_doubles": PITCH, "distinct_designs": CHANNELS if args.jitter else 1,
+                       "layout": args.layout, "row_pitch_doubles": pitch,
+                       "distinct_designs": CHANNELS if args.jitter else 1,
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                         "traffic_source": "profiles/r2_traffic.json (rocprofv3 --pmc passes of this command, committed; "
+                                           "not re-measured by this run)",
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,
                          "copy_ceiling_measured": copy_gbs,
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
+                         "kernel_ms_avg": kern_avg_s * 1e3,
+                         "single_launch_ms_avg": float(np.mean(kern_ms)), "single_launch_ms_min": float(np.min(kern_ms))},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(b, a)
+        if world == 1 and not args.no_extra and not args.jitter:
+            # compact same-run results for configs 3 and 5 (a few steps each, no CPU leg), so that the driver's
+            # default run also times the Toeplitz-MFMA FIR kernel and the single-stream split
+            del bank, xbuf, ybuf
+            torch.cuda.empty_cache()
+            import copy
+            other = {}
+            a3 = copy.copy(args)
+            a3.steps, a3.warmup, a3.no_cpu = 4, 1, True
+            other["config3_fir512"] = _compact(main_fir512(a3, emit=False))
+            torch.cuda.empty_cache()
+            a5 = copy.copy(args)
+            a5.steps, a5.warmup, a5.no_cpu = 8, 2, True
+            other["config5_stream16"] = _compact(main_stream16(a5, emit=False))
+            line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_fir512(args):
+def _compact(line):
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline")
+    return {k: line[k] for k in keep if k in line}
+
+
+def main_fir512(args, emit=True):
     """BASELINE.json config 3: 512-tap FIR low-pass, 65 536 channels x 64K samples per GPU.  One STEP =
     one RTFilterBank_updaten over the whole 65 536 x 65 536 block (32 GiB read + 32 GiB written), the
     state carried on (the stream simply continues with the same input block).  Dominant kernel:
@@ -337,13 +388,16 @@ def main_fir512(args):
                        "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TF,
-                         "traffic": measured_traffic("r1_fir512_traffic.json") if nch == 65536 else None,
+                         "traffic": measured_traffic("r2_fir512_traffic.json") if nch == 65536 else None,
                          "algorithmic_flops_per_launch": flops,
                          "hbm_gbs_at_16B_per_sample": samples * BYTES_PER_SAMPLE / kern_avg_s / 1e9,
                          "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_fir(b)
+        if not emit:
+            bank.close()
+            return line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -473,7 +527,7 @@ def main_mixed(args):
         dist.destroy_process_group()
 
 
-def main_stream16(args):
+def main_stream16(args, emit=True):
     """BASELINE.json config 5: ONE 2^30-sample stream through a 16th-order IIR (butterworth(8, 0.25, 0.75),
     na = nb = 17).  One STEP = RTFilter_updaten over the whole stream: on N GPUs rank r holds samples
     [r L, (r+1) L) resident, the ranks exchange the state hand-off vectors (dsp_amd.stream.split_update:
@@ -549,14 +603,14 @@ def main_stream16(args):
                        "parallelism": "time-split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (2 * measured_traffic("r1_config5_traffic.json")
+                         "traffic": (2 * measured_traffic("r2_config5_traffic.json")
                                      if world == 1 and args.stream_log2 == 30
-                                     and measured_traffic("r1_config5_traffic.json") else None),
+                                     and measured_traffic("r2_config5_traffic.json") else None),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
                          "note": "per-GPU bytes of one step (the run-up launch over the sub-chunks' tails, the main "
                                  "launch of the scan kernel over all sub-chunks, state copies) over the step's device "
                                  "time on rank 0; traffic = PMC bytes of the two launches "
-                                 "(profiles/r1_config5_traffic.json)",
+                                 "(profiles/r2_config5_traffic.json, committed; not re-measured by this run)",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         if world == 1 and not args.no_cpu:
@@ -575,6 +629,8 @@ def main_stream16(args):
             line["cpu_baseline"] = dict(value=reps * m / dt / 1e6, unit="Msamples/s", cores=1, kind=kind,
                                         sample="%d x 2^24 consecutive samples of the config-5 stream on one host core "
                                                "(one filter is serial in time on the CPU), %.1f s" % (reps, dt))
+        if not emit:
+            return line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

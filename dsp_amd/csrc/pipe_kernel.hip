@@ -210,6 +210,31 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = 0.0;
             v[N] = tailv;
+#ifdef EXP_ZS_RECUR
+            /* zero-state pass by the recurrence itself: 2N+1 FMAs per sample with the coefficients in SGPRs (one
+             * scalar batch per segment) instead of N FMAs per sample against 16 table batches, each an exposed
+             * trip to the scalar cache */
+            {
+                double zb[N + 1], za[N + 1];
+                load_coefs(zb, za);
+                constexpr int kBurst = PT / 4;
+#pragma unroll
+                for (int h = 0; h < PT / 2; h += kBurst) {
+                    d2 xq[kBurst];
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q)
+                        xq[q] = *reinterpret_cast<const d2 *>(row + (((h + q) << 4) ^ rx));
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q) {
+                        (void)iir_step_fused<N, kUnitA0>(xq[q].x, v, zb, za);
+                        (void)iir_step_fused<N, kUnitA0>(xq[q].y, v, zb, za);
+                    }
+                }
+            }
+            if (false) {
+#else
+            {
+#endif
             /* the row comes out of LDS in one burst; the table arrives in scalar batches of kZB samples
              * (<= 32 SGPRs each), so a batch's wait is not also a wait for LDS */
             d2 xr[PT / 2];
@@ -236,6 +261,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             if (tailv != 0.0) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gtab[PT * N + i], tailv, v[i]);
+            }
             }
             if (it == 0) stamp(8);
             if (it == 8) stamp(13);

@@ -66,6 +66,95 @@ __global__ void __launch_bounds__(256) copy_rows_stamped(const d2 *__restrict__ 
     }
 }
 
+/* Row copy with tail stealing: the balance experiment for the filter kernel's one-round launch.  One wave per
+ * workgroup; workgroup b owns row b and claims its 16 KiB segments front to back through claims[b] (low 16 bits:
+ * segments claimed by the owner, high 16: segments stolen from the END by other workgroups).  A workgroup whose row
+ * is exhausted probes 64 other rows, picks the one with the most unclaimed segments (>= min_rem) and takes its last
+ * unclaimed segment; with runup != 0 it also reads the segment in front of it (what the filter would need to
+ * rebuild the carried state).  No waiting anywhere: every loop ends when a claim fails or no victim is found. */
+template <int U>
+__global__ void __launch_bounds__(64) copy_rows_steal(const d2 *__restrict__ in, d2 *__restrict__ out, unsigned rows,
+                                                       unsigned nseg, size_t pitch16, unsigned *claims, int steal,
+                                                       int runup, unsigned min_rem, unsigned long long *stamps,
+                                                       double *sink)
+{
+    const unsigned b = blockIdx.x, lane = threadIdx.x;
+    const size_t seg16 = (size_t)64 * U;
+    unsigned long long t0 = 0;
+    if (lane == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    auto claim_own = [&]() -> unsigned {                    /* returns the segment index or ~0u */
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(&claims[b], 1u);
+        old = __builtin_amdgcn_readfirstlane(old);
+        const unsigned head = old & 0xffffu, stolen = old >> 16;
+        return head + stolen < nseg ? head : ~0u;
+    };
+    auto load_seg = [&](unsigned row, unsigned seg, d2(&v)[U]) {
+        const d2 *src = in + row * pitch16 + seg * seg16;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + lane + u * 64);
+    };
+    auto store_seg = [&](unsigned row, unsigned seg, const d2(&v)[U]) {
+        d2 *dst = out + row * pitch16 + seg * seg16;
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], dst + lane + u * 64);
+    };
+    d2 cur[U], nxt[U];
+    unsigned scur = claim_own();
+    unsigned snxt = claim_own();
+    if (scur != ~0u) load_seg(b, scur, cur);
+    unsigned own_done = 0, stolen_done = 0;
+    while (scur != ~0u) {
+        if (snxt != ~0u) load_seg(b, snxt, nxt);
+        const unsigned snn = snxt != ~0u ? claim_own() : ~0u;
+        store_seg(b, scur, cur);
+        ++own_done;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        scur = snxt;
+        snxt = snn;
+    }
+    double acc = 0.0;
+    for (int tries = 0; steal && tries < 64; ++tries) {
+        const unsigned cand = (b + 1 + 17 * lane) % rows;
+        const unsigned w = __hip_atomic_load(&claims[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned head = w & 0xffffu, st = w >> 16;
+        unsigned rem = head + st < nseg ? nseg - head - st : 0;
+        if (head == 0) rem = 0;                               /* owner not started */
+        unsigned best = rem, who = lane;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned ob = __shfl_xor(best, d, 64), ow = __shfl_xor(who, d, 64);
+            if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
+        }
+        if (best < min_rem) break;
+        const unsigned victim = (b + 1 + 17 * who) % rows;
+        unsigned old = 0;
+        if (lane == 0) old = atomicAdd(&claims[victim], 1u << 16);
+        old = __builtin_amdgcn_readfirstlane(old);
+        const unsigned h2 = old & 0xffffu, s2 = old >> 16;
+        if (h2 + s2 >= nseg) continue;                        /* lost the race: probe again */
+        const unsigned seg = nseg - 1 - s2;
+        if (runup && seg > 0) {
+            d2 r[U];
+            load_seg(victim, seg - 1, r);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += r[u].x;
+        }
+        load_seg(victim, seg, cur);
+        store_seg(victim, seg, cur);
+        ++stolen_done;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) {
+        stamps[4 * b + 0] = t0;
+        stamps[4 * b + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[4 * b + 2] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | (stolen_done << 8) | (own_done << 20);
+        stamps[4 * b + 3] = b;
+    }
+}
+
 int main()
 {
     const size_t rows = 1024, L = 65536;
@@ -130,6 +219,47 @@ int main()
         printf("\n    by row parity: even %.1f odd %.1f ; by XCC parity: even %.1f odd %.1f\n", by_par[0] / n_par[0],
                by_par[1] / n_par[1], by_xpar[0] / std::max(1, n_xpar[0]), by_xpar[1] / std::max(1, n_xpar[1]));
         fflush(stdout);
+    }
+    /* ---- tail stealing ---- */
+    {
+        const size_t pitch = ((size_t)1 << 20) + 128;
+        const unsigned nseg = 32;                               /* 64K doubles = 32 segments of 16 KiB */
+        unsigned *d_claims;
+        double *d_sink;
+        CHECK(hipMalloc(&d_claims, rows * 4));
+        CHECK(hipMalloc(&d_sink, 64));
+        struct SC { const char *name; int steal, runup; unsigned min_rem; };
+        const SC scs[] = {{"one wave per row, claims only (no stealing)", 0, 0, 2},
+                          {"tail stealing, min_rem 2", 1, 0, 2},
+                          {"tail stealing, min_rem 3", 1, 0, 3},
+                          {"tail stealing + run-up read, min_rem 2", 1, 1, 2},
+                          {"tail stealing + run-up read, min_rem 3", 1, 1, 3}};
+        for (const SC &c : scs) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                CHECK(hipMemset(d_claims, 0, rows * 4));
+                CHECK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL((copy_rows_steal<16>), dim3(rows), dim3(64), 0, 0, in, out, (unsigned)rows, nseg,
+                                   pitch / 2, d_claims, c.steal, c.runup, c.min_rem, d_st, d_sink);
+                CHECK(hipEventRecord(e1, 0));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            CHECK(hipMemcpy(st.data(), d_st, rows * 4 * 8, hipMemcpyDeviceToHost));
+            double mean = 0, mx = 0, mn = 1e30;
+            unsigned long total_stolen = 0, total_own = 0, max_stolen = 0;
+            for (size_t b = 0; b < rows; ++b) {
+                const double life = (double)(st[4 * b + 1] - st[4 * b]) / 100.0;
+                mean += life; mx = std::max(mx, life); mn = std::min(mn, life);
+                const unsigned sd = (st[4 * b + 2] >> 8) & 0xfff, od = (st[4 * b + 2] >> 20) & 0xfff;
+                total_stolen += sd; total_own += od; max_stolen = std::max<unsigned long>(max_stolen, sd);
+            }
+            printf("%-48s event %.1f us (%.0f GB/s)  life min %.1f mean %.1f max %.1f  segments own %lu stolen %lu (max %lu per WG)\n",
+                   c.name, best * 1e3, rows * L * 16 / (best * 1e-3) / 1e9, mn, mean / rows, mx, total_own, total_stolen, max_stolen);
+            fflush(stdout);
+        }
     }
     return 0;
 }
