@@ -38,12 +38,14 @@ def noalloc_max_doubles():
     return dspdll.RTFilterBank_noalloc_max_doubles()
 
 
-def _stream_ptr(stream):
+def _stream_ptr(stream, device=None):
+    """hipStream_t for the C ABI.  None = torch's current stream OF `device` (the bank's device, which need not be
+    torch's current device), or the default stream without torch."""
     if stream is None:
         try:
             import torch
             if torch.cuda.is_available():
-                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         except ImportError:
             pass
         return None
@@ -118,13 +120,13 @@ class FilterBank:
 
     def updaten_ptr(self, out_ptr, ld_out, in_ptr, ld_in, n, stream=None):
         _check(dspdll.RTFilterBank_updaten(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
-                                           ld_in, n, _stream_ptr(stream)), "RTFilterBank_updaten")
+                                           ld_in, n, _stream_ptr(stream, self.device)), "RTFilterBank_updaten")
 
     def updaten_ptr_noalloc(self, out_ptr, ld_out, in_ptr, ld_in, n, stream=None):
         """RTFilterBank_updaten_noalloc: the same update without any allocation (in-place FIR calls stage
         through the library's static device array; RTFB_ESIZE beyond noalloc_max_doubles())."""
         _check(dspdll.RTFilterBank_updaten_noalloc(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
-                                                   ld_in, n, _stream_ptr(stream)), "RTFilterBank_updaten_noalloc")
+                                                   ld_in, n, _stream_ptr(stream, self.device)), "RTFilterBank_updaten_noalloc")
 
     def __call__(self, x, out=None, stream=None):
         """x: (nch, n) float64 device tensor with contiguous rows.  Returns the output tensor."""
@@ -138,10 +140,10 @@ class FilterBank:
         return out
 
     def reset(self, stream=None):
-        _check(dspdll.RTFilterBank_reset(self._handle, _stream_ptr(stream)), "RTFilterBank_reset")
+        _check(dspdll.RTFilterBank_reset(self._handle, _stream_ptr(stream, self.device)), "RTFilterBank_reset")
 
     def sync_to_host(self, stream=None):
-        _check(dspdll.RTFilterBank_sync_to_host(self._handle, _stream_ptr(stream)), "RTFilterBank_sync_to_host")
+        _check(dspdll.RTFilterBank_sync_to_host(self._handle, _stream_ptr(stream, self.device)), "RTFilterBank_sync_to_host")
 
     @property
     def state_ld(self):
@@ -154,7 +156,7 @@ class FilterBank:
         ini = np.empty(self.nch, dtype=np.int32)
         _check(dspdll.RTFilterBank_get_state(self._handle, st.ctypes.data_as(C.POINTER(C.c_double)),
                                              fv.ctypes.data_as(C.POINTER(C.c_double)),
-                                             ini.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream)),
+                                             ini.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream, self.device)),
                "RTFilterBank_get_state")
         return st, fv, ini
 
@@ -170,7 +172,7 @@ class FilterBank:
             assert np.shape(state) == (self.nch, self.state_ld)
         _check(dspdll.RTFilterBank_set_state(self._handle, ptr(state, np.float64, C.c_double),
                                              ptr(fval, np.float64, C.c_double),
-                                             ptr(init, np.int32, C.c_int32), _stream_ptr(stream)),
+                                             ptr(init, np.int32, C.c_int32), _stream_ptr(stream, self.device)),
                "RTFilterBank_set_state")
 
 
@@ -178,5 +180,5 @@ def synth_fill(tensor, seed, chan0=0, n0=0, stream=None):
     """Fill a (nch, n) float64 device tensor with the SURVEY.md 8(d) synthetic input."""
     nch, n = tensor.shape
     _check(dspdll.dsp_synth_fill(C.c_void_p(tensor.data_ptr()), tensor.stride(0), nch, n, seed, chan0, n0,
-                                 _stream_ptr(stream)), "dsp_synth_fill")
+                                 _stream_ptr(stream, tensor.device)), "dsp_synth_fill")
     return tensor

@@ -145,6 +145,7 @@ _proto("RTFilterBank_from_filters", c_int, [POINTER(c_void_p), POINTER(c_void_p)
 _proto("RTFilterBank_from_designs", c_int,
        [POINTER(c_void_p), POINTER(RTFilterDesign_), c_size_t, POINTER(c_int32), c_size_t, c_int])
 _proto("dsp_scan_probe", c_int, [POINTER(RTFilterDesign_), POINTER(c_double)])
+_proto("dsp_bank_table_doubles", c_int, [POINTER(RTFilterDesign_), c_size_t, POINTER(c_size_t)])
 _proto("RTFilterBank_destroy", None, [c_void_p])
 _proto("RTFilterBank_channels", c_size_t, [c_void_p])
 _proto("RTFilterBank_set_mode", c_int, [c_void_p, c_int])
@@ -160,6 +161,7 @@ _proto("RTFilterBank_set_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c
 _proto("RTFilterBank_last_error", c_char_p, [])
 _proto("dsp_pool_alloc", c_int, [POINTER(c_void_p), c_size_t, c_int])
 _proto("dsp_pool_free", c_int, [c_void_p])
+_proto("dsp_pool_free_async", c_int, [c_void_p, c_void_p])
 _proto("dsp_pool_trim", c_int, [c_int])
 _proto("dsp_pool_bytes_in_use", c_size_t, [c_int])
 _proto("dsp_pool_bytes_cached", c_size_t, [c_int])

@@ -19,7 +19,9 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -119,8 +121,11 @@ int static_scratch_of(int device, double **ptr)
 struct Pool {
     std::mutex mu;
     struct Block { size_t bytes; int device; };
+    /* a cached block; `ready` != nullptr: freed with dsp_pool_free_async, reusable once that event (recorded on the
+     * freeing stream at the time of the free) has completed */
+    struct Cached { void *ptr; hipEvent_t ready; };
     std::unordered_map<void *, Block> live;                  /* handed out */
-    std::map<std::pair<int, size_t>, std::vector<void *>> cache;   /* (device, bytes) -> free */
+    std::map<std::pair<int, size_t>, std::vector<Cached>> cache;   /* (device, bytes) -> free */
     std::unordered_map<int, size_t> in_use, cached;
 
     static size_t bucket(size_t bytes)
@@ -150,14 +155,25 @@ int pool_alloc(void **out, size_t bytes, int device)
     {
         std::lock_guard<std::mutex> lk(p.mu);
         auto it = p.cache.find({device, b});
-        if (it != p.cache.end() && !it->second.empty()) {
-            void *ptr = it->second.back();
-            it->second.pop_back();
-            p.cached[device] -= b;
-            p.in_use[device] += b;
-            p.live[ptr] = {b, device};
-            *out = ptr;
-            return RTFB_OK;
+        if (it != p.cache.end()) {
+            /* newest first; a block whose free is still pending on its stream is passed over */
+            std::vector<Pool::Cached> &v = it->second;
+            for (size_t k = v.size(); k-- > 0;) {
+                if (v[k].ready) {
+                    if (hipEventQuery(v[k].ready) != hipSuccess) {
+                        (void)hipGetLastError();
+                        continue;
+                    }
+                    (void)hipEventDestroy(v[k].ready);
+                }
+                void *ptr = v[k].ptr;
+                v.erase(v.begin() + (long)k);
+                p.cached[device] -= b;
+                p.in_use[device] += b;
+                p.live[ptr] = {b, device};
+                *out = ptr;
+                return RTFB_OK;
+            }
         }
     }
     DeviceScope ds(device);
@@ -181,18 +197,37 @@ int pool_alloc(void **out, size_t bytes, int device)
     return RTFB_OK;
 }
 
-int pool_free(void *ptr)
+/* Return a block to the cache.  `ordered`: the block may still be in use by work already enqueued on `stream`;
+ * an event recorded there now gates its reuse (pool_alloc passes it over until the event has completed).
+ * Without `ordered` the caller vouches that the device is done with the block (the bank's own frees come after
+ * a stream or device synchronisation). */
+int pool_free(void *ptr, bool ordered = false, hipStream_t stream = nullptr)
 {
     if (!ptr) return RTFB_OK;
     Pool &p = pool();
+    Pool::Block blk;
+    {
+        std::lock_guard<std::mutex> lk(p.mu);
+        auto it = p.live.find(ptr);
+        if (it == p.live.end()) return fail(RTFB_EINVAL, "dsp_pool_free: pointer not from this pool");
+        blk = it->second;
+    }
+    hipEvent_t ready = nullptr;
+    if (ordered) {
+        DeviceScope ds(blk.device);
+        if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+        HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ready, stream);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(ready);
+            return fail_hip(e, "hipEventRecord");
+        }
+    }
     std::lock_guard<std::mutex> lk(p.mu);
-    auto it = p.live.find(ptr);
-    if (it == p.live.end()) return fail(RTFB_EINVAL, "dsp_pool_free: pointer not from this pool");
-    const Pool::Block blk = it->second;
-    p.live.erase(it);
+    p.live.erase(ptr);
     p.in_use[blk.device] -= blk.bytes;
     p.cached[blk.device] += blk.bytes;
-    p.cache[{blk.device, blk.bytes}].push_back(ptr);
+    p.cache[{blk.device, blk.bytes}].push_back({ptr, ready});
     return RTFB_OK;
 }
 
@@ -226,6 +261,7 @@ struct Design {
     int levels1 = kScanLevels;
     int gtab1_off = 0;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
+    bool has_tables = false;            /* scan tables built (false: the design's group is sequential-only) */
     bool scan_safe() const;
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
     bool fast_iir() const
@@ -240,6 +276,7 @@ struct Group {
     GroupClass cls;
     int order = 0;                      /* kIirFast: N */
     bool scan_safe = false;             /* kIirFast: every design passed the conditioning probe */
+    bool has_tables = true;             /* kIirFast: every design carries its scan tables          */
     bool unit_a0 = false;               /* kIirFast: every design has a[0] == 1.0               */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
     int state_ld = 1;
@@ -266,8 +303,6 @@ struct RTFilterBank {
     int device = 0;
     size_t nch = 0;
     int mode = RTFB_MODE_AUTO;
-    /* A/B switch for profiling: DSP_AMD_SCAN_VARIANT = 0 pipelined (default), 1 two-wave, 2 one-wave */
-    int scan_variant = std::getenv("DSP_AMD_SCAN_VARIANT") ? std::atoi(std::getenv("DSP_AMD_SCAN_VARIANT")) : 0;
     std::vector<Design> designs;
     std::vector<int32_t> design_of;     /* per channel */
     std::vector<Group> groups;
@@ -511,6 +546,22 @@ void free_bank_device(RTFilterBank *b)
     pool_free(b->d_pows);
 }
 
+/* From this many channels in a group the sequential (lane = channel) kernel fills the GPU and AUTO
+ * uses it; below, the time-parallel scan kernels. */
+constexpr size_t kAutoSeqMinChannels = 65536;
+constexpr size_t kSeqOnlyChannels = 2 * kAutoSeqMinChannels;   /* orders <= 8: sequential in every mode from here */
+
+/* Doubles of scan tables one design owns in `pows` (layout: A^(64 2^k) | G64 | A^(32 2^k) | G32 | row propagators). */
+size_t design_table_doubles(const Design &d, bool with_ttab)
+{
+    if (!d.has_tables) return 0;
+    const size_t N = (size_t)d.nb - 1;
+    size_t n = (size_t)kScanLevels * N * N + ((size_t)kScanT + 1) * N + (size_t)kScan2Levels * N * N +
+               ((size_t)kScan2T + 1) * N;
+    if (N <= (size_t)kScan2MaxOrder && with_ttab) n += (size_t)kWave * N * N;
+    return n;
+}
+
 /* Common tail of both constructors: designs + design_of are filled in;
  * init_state (nch x state_ld, may be empty = zeros), init_fval, init_init
  * give the starting per-channel fields. */
@@ -525,32 +576,87 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         if (rc0) return rc0;
     }
 
-    /* design tables */
+    /* design tables.  Offsets are 32-bit in the kernels' view (GroupView): sizes are laid out first and
+     * checked, then the tables of the designs are built in parallel, each into its own slice. */
     std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, levels1, gtab1_off, nb, na, kind;
     std::vector<double> coefs, pows;
     size_t ld = 1;
-    for (Design &d : bk->designs) {
-        d.coef_off = (int)coefs.size();
-        coefs.insert(coefs.end(), d.b.begin(), d.b.end());
-        coefs.insert(coefs.end(), d.a.begin(), d.a.end());
-        d.pow_off = (int)pows.size();
-        if (d.fast_iir()) {
-            scan_powers(d, kScanT, kScanLevels, pows);
-            const std::vector<double> mine(pows.begin() + d.pow_off, pows.end());
-            d.scan_error = scan_probe(d, mine);
-            d.levels1 = scan2_levels(&pows[d.pow_off], d.nb - 1, kScanLevels);
-            d.gtab1_off = (int)pows.size();
-            scan2_gtable(d, kScanT, pows);
-            d.pow2_off = (int)pows.size();
-            scan_powers(d, kScan2T, kScan2Levels, pows);
-            d.levels2 = scan2_levels(&pows[d.pow2_off], d.nb - 1);
-            d.gtab_off = (int)pows.size();
-            scan2_gtable(d, kScan2T, pows);
-            if (d.nb - 1 <= kScan2MaxOrder && bk->designs.size() <= kMaxPipeDesigns) {
-                d.ttab_off = (int)pows.size();
-                pipe_ttable(d, kScan2T, pows);
-            }
+    {
+        /* Designs whose launch group can never take a scan kernel carry no scan tables and skip the
+         * conditioning probe: orders <= 8 in a class of >= 2 * kAutoSeqMinChannels channels run the
+         * lane-per-channel kernel in every mode (RTFilterBank_updaten). */
+        std::map<int, size_t> class_channels;                    /* fast-IIR class -> channels */
+        for (size_t c = 0; c < bk->nch; ++c) {
+            const Design &d = bk->designs[bk->design_of[c]];
+            if (d.fast_iir()) class_channels[2 * (d.nb - 1) + (d.a[0] == 1.0 ? 1 : 0)]++;
         }
+        const bool with_ttab = bk->designs.size() <= kMaxPipeDesigns;
+        size_t ncoef = 0, npow = 0;
+        for (Design &d : bk->designs) {
+            d.has_tables = false;
+            if (d.fast_iir()) {
+                const int N = d.nb - 1;
+                const auto it = class_channels.find(2 * N + (d.a[0] == 1.0 ? 1 : 0));
+                const size_t width = it == class_channels.end() ? 0 : it->second;
+                d.has_tables = width > 0 && !(N <= kScan2MaxOrder && width >= kSeqOnlyChannels);
+            }
+            ncoef += (size_t)d.nb + (size_t)d.na;
+            npow += design_table_doubles(d, with_ttab);
+        }
+        if (ncoef > (size_t)INT32_MAX || npow > (size_t)INT32_MAX)
+            return fail(RTFB_ESIZE, "the bank's design tables exceed 2^31 doubles (" + std::to_string(npow) +
+                                        " of scan tables for " + std::to_string(bk->designs.size()) +
+                                        " designs); split the bank");
+        pows.assign(std::max<size_t>(npow, 1), 0.0);
+        coefs.reserve(ncoef);
+        size_t poff = 0;
+        for (Design &d : bk->designs) {
+            d.coef_off = (int)coefs.size();
+            coefs.insert(coefs.end(), d.b.begin(), d.b.end());
+            coefs.insert(coefs.end(), d.a.begin(), d.a.end());
+            d.pow_off = (int)poff;
+            poff += design_table_doubles(d, with_ttab);
+        }
+        /* build: one design at a time per worker, no shared state beyond the disjoint slices */
+        std::atomic<size_t> next{0};
+        const size_t nd = bk->designs.size();
+        auto worker = [&]() {
+            std::vector<double> mine;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= nd) break;
+                Design &d = bk->designs[i];
+                if (!d.has_tables) continue;
+                mine.clear();
+                const size_t base = (size_t)d.pow_off;
+                scan_powers(d, kScanT, kScanLevels, mine);
+                d.scan_error = scan_probe(d, mine);
+                d.levels1 = scan2_levels(mine.data(), d.nb - 1, kScanLevels);
+                d.gtab1_off = (int)(base + mine.size());
+                scan2_gtable(d, kScanT, mine);
+                d.pow2_off = (int)(base + mine.size());
+                const size_t p2 = mine.size();
+                scan_powers(d, kScan2T, kScan2Levels, mine);
+                d.levels2 = scan2_levels(&mine[p2], d.nb - 1);
+                d.gtab_off = (int)(base + mine.size());
+                scan2_gtable(d, kScan2T, mine);
+                if (d.nb - 1 <= kScan2MaxOrder && with_ttab) {
+                    d.ttab_off = (int)(base + mine.size());
+                    pipe_ttable(d, kScan2T, mine);
+                }
+                std::copy(mine.begin(), mine.end(), pows.begin() + (long)base);
+            }
+        };
+        size_t nthreads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16,
+                                            (nd + 7) / 8});
+        if (nthreads <= 1) worker();
+        else {
+            std::vector<std::thread> pool_threads;
+            for (size_t t = 0; t < nthreads; ++t) pool_threads.emplace_back(worker);
+            for (std::thread &t : pool_threads) t.join();
+        }
+    }
+    for (Design &d : bk->designs) {
         gtab_off.push_back(d.gtab_off);
         ttab_off.push_back(d.ttab_off);
         levels1.push_back(d.levels1);
@@ -589,6 +695,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         g.chans.push_back((int32_t)c);
         g.state_ld = std::max(g.state_ld, d.state_slots());
         g.levels2_max = std::max(g.levels2_max, d.levels2);
+        if (d.fast_iir() && !d.has_tables) g.has_tables = false;
         if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
         if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
         if (g.single_design == -2) g.single_design = bk->design_of[c];
@@ -608,7 +715,6 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     if ((rc = upload(&bk->d_na, na, device))) return rc;
     if ((rc = upload(&bk->d_kind, kind, device))) return rc;
     if ((rc = upload(&bk->d_coefs, coefs, device))) return rc;
-    if (pows.empty()) pows.push_back(0.0);
     if ((rc = upload(&bk->d_pows, pows, device))) return rc;
 
     for (Group &g : bk->groups) {
@@ -679,10 +785,6 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     return v;
 }
 
-/* From this many channels in a group the sequential (lane = channel) kernel fills the GPU and AUTO
- * uses it; below, the time-parallel scan kernels. */
-constexpr size_t kAutoSeqMinChannels = 65536;
-
 int validate_design(const RTFilterDesign &d)
 {
     if (d.kind != RTFB_KIND_IIR && d.kind != RTFB_KIND_FIR && d.kind != RTFB_KIND_FIR_PARTIAL)
@@ -718,7 +820,32 @@ int dsp_device_count(void)
 }
 
 int dsp_pool_alloc(void **dev_ptr, size_t bytes, int device) { return pool_alloc(dev_ptr, bytes, device); }
-int dsp_pool_free(void *dev_ptr) { return pool_free(dev_ptr); }
+
+/* hipFree semantics: the device is synchronised first, so no kernel on any stream can still be using the block
+ * when the next dsp_pool_alloc hands it out.  Real-time callers use dsp_pool_free_async. */
+int dsp_pool_free(void *dev_ptr)
+{
+    if (!dev_ptr) return RTFB_OK;
+    int device = -1;
+    {
+        Pool &p = pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        auto it = p.live.find(dev_ptr);
+        if (it == p.live.end()) return fail(RTFB_EINVAL, "dsp_pool_free: pointer not from this pool");
+        device = it->second.device;
+    }
+    {
+        DeviceScope ds(device);
+        if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return pool_free(dev_ptr);
+}
+
+int dsp_pool_free_async(void *dev_ptr, void *hip_stream)
+{
+    return pool_free(dev_ptr, true, static_cast<hipStream_t>(hip_stream));
+}
 
 int dsp_pool_trim(int device)
 {
@@ -728,7 +855,10 @@ int dsp_pool_trim(int device)
         std::lock_guard<std::mutex> lk(p.mu);
         for (auto &kv : p.cache) {
             if (kv.first.first != device) continue;
-            for (void *ptr : kv.second) victims.push_back(ptr);
+            for (const Pool::Cached &c : kv.second) {
+                victims.push_back(c.ptr);
+                if (c.ready) (void)hipEventDestroy(c.ready);      /* hipFree below synchronises by itself */
+            }
             p.cached[device] -= kv.first.second * kv.second.size();
             kv.second.clear();
         }
@@ -800,6 +930,30 @@ int dsp_scan_probe(const RTFilterDesign *design, double *rel_error)
     std::vector<double> pows;
     scan_powers(d, kScanT, kScanLevels, pows);
     *rel_error = scan_probe(d, pows);
+    return RTFB_OK;
+}
+
+/* Host arithmetic only (no device needed): doubles of scan tables a bank of these designs would carry if every
+ * design kept its tables, and whether that fits the kernels' 32-bit table offsets (RTFB_ESIZE if not) -- the check
+ * RTFilterBank_from_designs / _from_filters apply before building anything. */
+int dsp_bank_table_doubles(const RTFilterDesign *designs, size_t ndesign, size_t *doubles)
+{
+    if (!designs || !ndesign || !doubles) return fail(RTFB_EINVAL, "dsp_bank_table_doubles: NULL or empty argument");
+    size_t total = 0, ncoef = 0;
+    for (size_t i = 0; i < ndesign; ++i) {
+        int rc = validate_design(designs[i]);
+        if (rc) return rc;
+        Design d;
+        d.kind = designs[i].kind;
+        d.nb = (int)designs[i].nb;
+        d.na = d.kind == RTFB_KIND_IIR ? (int)designs[i].na : 0;
+        d.has_tables = d.fast_iir();
+        total += design_table_doubles(d, ndesign <= kMaxPipeDesigns);
+        ncoef += (size_t)d.nb + (size_t)d.na;
+    }
+    *doubles = total;
+    if (total > (size_t)INT32_MAX || ncoef > (size_t)INT32_MAX)
+        return fail(RTFB_ESIZE, "the bank's design tables exceed 2^31 doubles; split the bank");
     return RTFB_OK;
 }
 
@@ -1007,9 +1161,7 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
                 fio.in = g.d_scratch;
                 fio.ld_in = n;
             }
-            static const int mfma_min =                       /* DSP_AMD_FIR_MFMA_MIN: A/B switch for profiling */
-                std::getenv("DSP_AMD_FIR_MFMA_MIN") ? std::atoi(std::getenv("DSP_AMD_FIR_MFMA_MIN")) : kFirMfmaMinTaps;
-            v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= mfma_min) ? 1 : 0;
+            v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= kFirMfmaMinTaps) ? 1 : 0;
             HIP_TRY(launch_fir(v, fio, s));
             if (fir_uses_state_swap(v, fio)) std::swap(g.d_state, g.d_state_alt);
             continue;
@@ -1028,15 +1180,14 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
          * stay on the lane-per-channel kernel. */
         const size_t seq_from = g.order <= kScan2MaxOrder ? 2 * kAutoSeqMinChannels
                                 : (n >= (size_t)kWave * kScanT ? (size_t)-1 : kAutoSeqMinChannels);
-        bool seq = bank->mode == RTFB_MODE_SEQUENTIAL ||
+        bool seq = bank->mode == RTFB_MODE_SEQUENTIAL || !g.has_tables ||
                    (bank->mode == RTFB_MODE_AUTO && (!g.scan_safe || g.chans.size() >= seq_from));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
-        else if (g.order <= kScan2MaxOrder && bank->scan_variant == 0 &&
-                 bank->designs.size() <= kMaxPipeDesigns)
-            HIP_TRY(launch_iir_pipe(g.order, v, io, s));
-        else if (g.order <= kScan2MaxOrder && bank->scan_variant <= 1) HIP_TRY(launch_iir_scan2(g.order, v, io, s));
-        else HIP_TRY(launch_iir_scan(g.order, v, io, s));
+        else if (g.order <= kScan2MaxOrder && bank->designs.size() <= kMaxPipeDesigns)
+            HIP_TRY(launch_iir_pipe(g.order, v, io, s));            /* per-design row propagators resident */
+        else if (g.order <= kScan2MaxOrder) HIP_TRY(launch_iir_scan2(g.order, v, io, s));   /* > 1024 designs */
+        else HIP_TRY(launch_iir_scan(g.order, v, io, s));           /* orders 9..16 */
     }
     return RTFB_OK;
 }
@@ -1430,9 +1581,7 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         /* sub-chunk: at least 4 decay lengths (the run-up costs M/Lc extra) and 8192 samples */
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
-        static const size_t max_split =                       /* DSP_AMD_STREAM_SPLIT: A/B switch for profiling */
-            std::getenv("DSP_AMD_STREAM_SPLIT") ? (size_t)std::atoll(std::getenv("DSP_AMD_STREAM_SPLIT")) : kStreamMaxSplit;
-        size_t C = st->decay ? std::min(max_split, n / lmin) : 0;
+        size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
         if (C < kStreamMinSplit) {                    /* sequential: the one-channel bank itself */
             int rc = RTFilterBank_updaten(st->one, out, n, in, n, n, s);
             if (rc) return rc;

@@ -375,7 +375,8 @@ fir_epilogue_kernel(GroupView g, BlockIO io)
 
 /* ------------------------------------------------------------------------ */
 /* Long-tap FIR as a Toeplitz-tile contraction on the FP64 matrix cores         */
-/* (v_mfma_f64_16x16x4_f64) -- the only place this library uses MFMA.           */
+/* (v_mfma_f64_16x16x4_f64).  The other MFMA user is the order 9..16 IIR scan   */
+/* (iir_scan16_kernel, kernels.hip).                                            */
 /*                                                                              */
 /* Steady-state outputs (at least K-1 regular samples behind them) are          */
 /*     y[m] = s[K-1] + sum_k b[k] x[m-k].                                        */

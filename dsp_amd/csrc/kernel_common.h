@@ -31,13 +31,8 @@ __device__ __forceinline__ cint_p as_const(const int32_t *p)
  * output stores that these kernels keep in flight across phases. */
 /* x is read once and y written once per launch: the nontemporal hint on both sides of a streaming kernel is
  * worth 4 % of HBM bandwidth on MI355X (tools/copy_nt.py: 4.89 -> 5.10 TB/s for a row copy; either side alone: 1 %). */
-#ifdef EXP_NO_NT
-__device__ __forceinline__ d2 stream_load(const d2 *p) { return *p; }
-__device__ __forceinline__ void stream_store(d2 *p, d2 v) { *p = v; }
-#else
 __device__ __forceinline__ d2 stream_load(const d2 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stream_store(d2 *p, d2 v) { __builtin_nontemporal_store(v, p); }
-#endif
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 

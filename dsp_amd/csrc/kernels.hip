@@ -349,135 +349,6 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
     ylast = shfl_f64(y, jlast);
 }
 
-/* kStamp: diagnostic instantiation only (never the shipped path).  Per-phase
- * s_memtime deltas are summed per wavefront and written to g.aux (as 8
- * uint64 per channel): park, prefetch issue, pass 1, combine, pass 2, store. */
-template <int N, int T, bool kUnitA0, bool kStamp = false>
-__global__ void __launch_bounds__(kWave)
-iir_scan_kernel(GroupView g, BlockIO io)
-{
-    using TG = Tile<T>;
-    constexpr int kSeg = kWave * T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int lane = threadIdx.x;
-    const int gi = blockIdx.x;                       /* one wavefront per channel */
-    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
-    const int dsn = as_const(g.design)[gi];
-
-    double b[N + 1], a[N + 1], carry[N + 1];
-    {
-        cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
-#pragma unroll
-        for (int i = 0; i <= N; ++i) {
-            b[i] = cf[i];
-            a[i] = cf[N + 1 + i];
-        }
-        const double *st = g.state + (size_t)gi * g.state_ld;
-#pragma unroll
-        for (int i = 0; i <= N; ++i) carry[i] = st[i];
-    }
-    cdouble_p pw = as_const(g.pows) + as_const(g.pow_off)[dsn];
-    cdouble_p gtab = as_const(g.pows) + as_const(g.gtab1_off)[dsn];
-    const int nlev = as_const(g.levels1)[dsn];
-    double ylast = g.fval[gi];
-    bool need_seed = g.init[gi] != 0;
-
-    const size_t n = io.n;
-    const double *src = io.in + (size_t)chan * io.ld_in;
-    double *dst = io.out + (size_t)chan * io.ld_out;
-
-    d2 pre[TG::kLoads];
-    auto fetch = [&](size_t base) {
-        const size_t left = n - base;
-        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
-        if (seg_len == kSeg && io.aligned16) {
-#pragma unroll
-            for (int i = 0; i < TG::kLoads; ++i)
-                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
-        } else {
-#pragma unroll
-            for (int i = 0; i < TG::kLoads; ++i) {
-                const int e = 2 * (i * kWave + lane);
-                d2 v = {0.0, 0.0};
-                if (e < seg_len) v.x = src[base + e];
-                if (e + 1 < seg_len) v.y = src[base + e + 1];
-                pre[i] = v;
-            }
-        }
-    };
-
-    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long t_prev = 0;
-    auto stamp = [&](int slot) {
-        if (kStamp) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            acc_t[slot] += now - t_prev;
-            t_prev = now;
-        }
-    };
-
-    fetch(0);
-    if (kStamp) t_prev = __builtin_readcyclecounter();
-    for (size_t base = 0; base < n; base += kSeg) {
-        const size_t left = n - base;
-        const int seg_len = left < (size_t)kSeg ? (int)left : kSeg;
-
-        /* park the prefetched segment in LDS (row = lane-chunk, padded) */
-#pragma unroll
-        for (int i = 0; i < TG::kLoads; ++i) {
-            const int p = i * kWave + lane;
-            *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
-                                    (p % TG::kPiecesPerRow) * 16) = pre[i];
-        }
-        wave_sync();
-        stamp(0);
-        if (base + kSeg < n) fetch(base + kSeg);     /* next segment's loads fly during compute */
-        stamp(1);
-
-        if (seg_len == kSeg && !need_seed)
-            scan_segment<N, T, kUnitA0, false, kStamp>(smem, lane, seg_len, false, b, a, pw, gtab, nlev, carry,
-                                                       ylast, acc_t, t_prev);
-        else
-            scan_segment<N, T, kUnitA0, true, kStamp>(smem, lane, seg_len, need_seed, b, a, pw, gtab, nlev, carry,
-                                                      ylast, acc_t, t_prev);
-        need_seed = false;
-        wave_sync();
-
-        if (seg_len == kSeg && io.aligned16) {
-#pragma unroll 8
-            for (int i = 0; i < TG::kLoads; ++i) {
-                const int p = i * kWave + lane;
-                stream_store(reinterpret_cast<d2 *>(dst + base + 2 * p), *reinterpret_cast<const d2 *>(
-                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16));
-            }
-        } else {
-#pragma unroll 4
-            for (int i = 0; i < TG::kLoads; ++i) {
-                const int p = i * kWave + lane;
-                const int e = 2 * p;
-                const d2 v = *reinterpret_cast<const d2 *>(
-                    smem + (p / TG::kPiecesPerRow) * TG::kRowBytes + (p % TG::kPiecesPerRow) * 16);
-                if (e < seg_len) dst[base + e] = v.x;
-                if (e + 1 < seg_len) dst[base + e + 1] = v.y;
-            }
-        }
-        wave_sync();
-        stamp(5);
-    }
-
-    if (lane == 0) {
-        double *st = g.state + (size_t)gi * g.state_ld;
-#pragma unroll
-        for (int i = 0; i <= N; ++i) st[i] = carry[i];
-        g.fval[gi] = ylast;
-        g.init[gi] = 0;
-        if (kStamp) {
-            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(g.aux) + (size_t)gi * 8;
-            for (int i = 0; i < 6; ++i) dbg[i] = acc_t[i];
-        }
-    }
-}
 
 /* ------------------------------------------------------------------------ */
 /* K_scan16: orders 9..16, the scan kernel with its two GEMM-shaped stages on */
@@ -991,21 +862,13 @@ hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t
                             size_t n, int threads, int seg, hipStream_t s)
 {
     /* the 256-thread variant carries the nontemporal hint on both sides like the filter kernels (the faster
-     * copy: 5.10 vs 4.89 TB/s); DSP_COPY_NT = 0 none, 1 loads only, 2 stores only for diagnostics */
-    const char *nt = std::getenv("DSP_COPY_NT");
-    const int ntm = nt ? std::atoi(nt) : 3;
-    if (threads == 256 && ntm == 1)
-        hipLaunchKernelGGL((copy_rows_kernel<256, 1>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
-    else if (threads == 256 && ntm == 2)
-        hipLaunchKernelGGL((copy_rows_kernel<256, 2>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
-    else if (threads == 256 && ntm == 3)
+     * copy: 5.10 vs 4.89 TB/s, either side alone 1 %) */
+    if (threads == 256)
         hipLaunchKernelGGL((copy_rows_kernel<256, 3>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
     else if (threads == 64)
         hipLaunchKernelGGL(copy_rows_kernel<64>, dim3((unsigned)nch), dim3(64), 0, s, out, ld_out, in, ld_in, n, seg);
-    else if (threads == 128)
-        hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg);
     else
-        hipLaunchKernelGGL(copy_rows_kernel<256>, dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+        hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg);
     return hipGetLastError();
 }
 
@@ -1025,45 +888,20 @@ static hipError_t launch_seq_n(const GroupView &g, const BlockIO &io, hipStream_
     return hipGetLastError();
 }
 
-/* orders 9..16: the MFMA variant unless DSP_AMD_SCAN16=0 (A/B switch, read once) */
-static bool scan16_enabled()
-{
-    static const bool on = [] {
-        const char *e = std::getenv("DSP_AMD_SCAN16");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
+/* orders 9..16: the scan kernel with its GEMM-shaped stages on the matrix cores (orders <= 8 have their own
+ * two-wave kernels: pipe_kernel.hip, scan2_kernel.hip) */
 template <int N>
 static hipError_t launch_scan_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
-    if constexpr (N > 8 && kScanT == 64) {
-        if (scan16_enabled()) {
-            if (N == 16 && g.unit_a0 && g.aux)       /* diagnostic build with phase stamps */
-                hipLaunchKernelGGL((iir_scan16_kernel<16, kScanT, true, true>), dim3(g.count), dim3(kWave),
-                                   Tile<kScanT>::kBytes, s, g, io);
-            else if (g.unit_a0)
-                hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
-                                   Tile<kScanT>::kBytes, s, g, io);
-            else
-                hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, false>), dim3(g.count), dim3(kWave),
-                                   Tile<kScanT>::kBytes, s, g, io);
-            return hipGetLastError();
-        }
-    }
-    if constexpr (N == 8 || N == 16) {
-        if (g.unit_a0 && g.aux) {                /* diagnostic build with phase stamps */
-            hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, true, true>), dim3(g.count), dim3(kWave),
-                               Tile<kScanT>::kBytes, s, g, io);
-            return hipGetLastError();
-        }
-    }
-    if (g.unit_a0)
-        hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
+    static_assert(N > 8 && kScanT == 64, "iir_scan16_kernel serves orders 9..16");
+    if (N == 16 && g.unit_a0 && g.aux)       /* diagnostic build with phase stamps */
+        hipLaunchKernelGGL((iir_scan16_kernel<16, kScanT, true, true>), dim3(g.count), dim3(kWave),
+                           Tile<kScanT>::kBytes, s, g, io);
+    else if (g.unit_a0)
+        hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, true>), dim3(g.count), dim3(kWave),
                            Tile<kScanT>::kBytes, s, g, io);
     else
-        hipLaunchKernelGGL((iir_scan_kernel<N, kScanT, false>), dim3(g.count), dim3(kWave),
+        hipLaunchKernelGGL((iir_scan16_kernel<N, kScanT, false>), dim3(g.count), dim3(kWave),
                            Tile<kScanT>::kBytes, s, g, io);
     return hipGetLastError();
 }
@@ -1087,7 +925,7 @@ hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hip
 {
     switch (order) {
 #define X(N) case N: return launch_scan_n<N>(g, io, s);
-        DSP_FOR_EACH_ORDER(X)
+        X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X
     }
     return hipErrorInvalidValue;

@@ -55,14 +55,12 @@ constexpr int kPLevels = 6;                 /* log2(64) */
  * arrival order on the CU as far as the dispatch order tells (blockIdx / 256). */
 __device__ __forceinline__ void rotate_priority(int k)
 {
-#ifndef EXP_NO_PRIO
     switch (k & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
     }
-#endif
 }
 
 template <int N, bool kUnitA0, bool kWhole>

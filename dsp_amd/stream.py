@@ -51,7 +51,7 @@ class FilterStream:
 
     # ---- the path ----
     def updaten_ptr(self, out_ptr, in_ptr, n, stream=None):
-        _check(dspdll.RTFilterStream_updaten(self._h, C.c_void_p(out_ptr), C.c_void_p(in_ptr), n, _stream_ptr(stream)),
+        _check(dspdll.RTFilterStream_updaten(self._h, C.c_void_p(out_ptr), C.c_void_p(in_ptr), n, _stream_ptr(stream, self.device)),
                "RTFilterStream_updaten")
 
     def __call__(self, x, out=None, stream=None):
@@ -74,10 +74,10 @@ class FilterStream:
         return out
 
     def reset(self, stream=None):
-        _check(dspdll.RTFilterStream_reset(self._h, _stream_ptr(stream)), "RTFilterStream_reset")
+        _check(dspdll.RTFilterStream_reset(self._h, _stream_ptr(stream, self.device)), "RTFilterStream_reset")
 
     def sync_to_host(self, stream=None):
-        _check(dspdll.RTFilterStream_sync_to_host(self._h, _stream_ptr(stream)), "RTFilterStream_sync_to_host")
+        _check(dspdll.RTFilterStream_sync_to_host(self._h, _stream_ptr(stream, self.device)), "RTFilterStream_sync_to_host")
 
     @property
     def decay_length(self):
@@ -97,19 +97,19 @@ class FilterStream:
         return torch.zeros(self.pack_len, dtype=torch.float64, device=torch.device("cuda", self.device))
 
     def export_state(self, pack, stream=None):
-        _check(dspdll.RTFilterStream_export_state(self._h, C.c_void_p(pack.data_ptr()), _stream_ptr(stream)),
+        _check(dspdll.RTFilterStream_export_state(self._h, C.c_void_p(pack.data_ptr()), _stream_ptr(stream, self.device)),
                "RTFilterStream_export_state")
         return pack
 
     def import_state(self, pack, stream=None):
-        _check(dspdll.RTFilterStream_import_state(self._h, C.c_void_p(pack.data_ptr()), _stream_ptr(stream)),
+        _check(dspdll.RTFilterStream_import_state(self._h, C.c_void_p(pack.data_ptr()), _stream_ptr(stream, self.device)),
                "RTFilterStream_import_state")
 
     def tail_state(self, x, pack, stream=None):
         """Hand-off vector after x (zero-state response of its last decay_length samples).
         Returns False when the design or the chunk does not allow it (RTFB_EUNSUPPORTED)."""
         rc = dspdll.RTFilterStream_tail_state(self._h, C.c_void_p(x.data_ptr()), x.numel(),
-                                              C.c_void_p(pack.data_ptr()), _stream_ptr(stream))
+                                              C.c_void_p(pack.data_ptr()), _stream_ptr(stream, self.device))
         if rc == RTFB_EUNSUPPORTED:
             return False
         _check(rc, "RTFilterStream_tail_state")
@@ -122,7 +122,7 @@ class FilterStream:
         ini = np.zeros(1, dtype=np.int32)
         _check(dspdll.RTFilterStream_get_state(self._h, st.ctypes.data_as(C.POINTER(C.c_double)),
                                                fv.ctypes.data_as(C.POINTER(C.c_double)),
-                                               ini.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream)),
+                                               ini.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream, self.device)),
                "RTFilterStream_get_state")
         return st, float(fv[0]), int(ini[0])
 

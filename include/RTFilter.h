@@ -23,14 +23,8 @@
 extern "C" {
 #endif
 
-/* ref: include/dsputils.h:1-12 (EXPORT = default visibility on Linux) */
-#ifndef EXPORT
-#  if defined(__GNUC__)
-#    define EXPORT __attribute__((visibility("default")))
-#  else
-#    define EXPORT
-#  endif
-#endif
+/* ref: include/RTFilter.h:4 pulls <dsputils.h> (EXPORT = default visibility on Linux) */
+#include "dsputils.h"
 
 /* ref: include/RTFilter.h:9-20 -- allocator hooks, overridable at build time */
 #ifndef DSP_MALLOC
@@ -166,6 +160,19 @@ EXPORT int chebyshev1(RTIIRFilter *rtif, size_t order, double ripple, double wl,
 EXPORT int chebyshev2(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu, /* ref :168-169 */
                       unsigned int flags, rtf_sample_fn initialize);
 EXPORT int thiran(RTIIRFilter *rtif, size_t order, double tau, rtf_sample_fn initialize);   /* ref :171, c:1459-1495 */
+
+#if !defined(__STDC_NO_COMPLEX__) && !defined(__cplusplus)
+#include <complex.h>
+#ifndef DEFAULT_COMPLEX_TOLERANCE
+#define DEFAULT_COMPLEX_TOLERANCE 1e-7                                                      /* ref :176-178 */
+#endif
+/* ref :180-181, marked "internal only" there: an unfinished routine that prints debug text, overwrites the
+ * filter's bank with intermediate values and returns non-zero on every path (src/RTFilter.c:1760-1825).
+ * Exported for link compatibility: validates its arguments like the reference (1 on NULL / empty /
+ * wl == wu) and otherwise reports failure (1) WITHOUT touching the filter. */
+EXPORT int pzg_to_RTIIRFilter(RTIIRFilter *rtif, double complex *poles, size_t N, double complex *zeros,
+                              size_t M, double gain, double wl, double wu);
+#endif
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,13 @@ EXPORT int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *
  * kernel in AUTO mode.  RTFB_EUNSUPPORTED unless IIR with na == nb <= 17. */
 EXPORT int dsp_scan_probe(const RTFilterDesign *design, double *rel_error);
 
+/* Host arithmetic only: doubles of per-design scan tables a bank of these designs carries at most (fast IIR
+ * designs: matrix powers, zero-state response tables, row propagators).  The kernels address those tables with
+ * 32-bit offsets; RTFB_ESIZE (here and from the bank constructors) when a bank would exceed 2^31 doubles --
+ * about 1.3e6 distinct order-8 or 4.4e5 distinct order-16 designs.  Groups of >= 131072 channels of order <= 8
+ * run the lane-per-channel kernel in every mode and carry no tables at all. */
+EXPORT int dsp_bank_table_doubles(const RTFilterDesign *designs, size_t ndesign, size_t *doubles);
+
 EXPORT void   RTFilterBank_destroy(RTFilterBank *bank);
 EXPORT size_t RTFilterBank_channels(const RTFilterBank *bank);
 EXPORT int    RTFilterBank_set_mode(RTFilterBank *bank, int mode);
@@ -137,7 +144,12 @@ EXPORT const char *RTFilterBank_last_error(void);
  * tables (sized for 288 GB of HBM3E: blocks are reused, not re-allocated per
  * call).  Thread-safe. */
 EXPORT int    dsp_pool_alloc(void **dev_ptr, size_t bytes, int device);
+/* dsp_pool_free: like hipFree, synchronises the device first (no stream can still be using the block when it is
+ * handed out again).  dsp_pool_free_async: stream-ordered and non-blocking -- the block returns to the cache at
+ * once but is passed over by dsp_pool_alloc until the work enqueued on `hip_stream` before this call has
+ * completed (an event recorded there gates the reuse). */
 EXPORT int    dsp_pool_free(void *dev_ptr);
+EXPORT int    dsp_pool_free_async(void *dev_ptr, void *hip_stream);
 EXPORT int    dsp_pool_trim(int device);               /* release cached blocks to the driver */
 EXPORT size_t dsp_pool_bytes_in_use(int device);
 EXPORT size_t dsp_pool_bytes_cached(int device);

@@ -30,12 +30,7 @@ EXPORT int filter_response_ab(double complex *gain, size_t ng, double *a, size_t
  * pole j together, in index order (ref: src/filterutils.c:66-81) -- same operations, same bits. */
 EXPORT int filter_response_pzg(double complex *gain, size_t ng, double complex *zeros, size_t nz,
                                double complex *poles, size_t np, double kgain, double *freq);
-/* Declared in the reference's RTFilter.h:180-181 and marked "internal only" there: an unfinished routine that
- * prints debug text, overwrites the filter's bank with intermediate values and returns non-zero on every
- * path (ref: src/RTFilter.c:1760-1825).  Exported for link compatibility: validates its arguments like the
- * reference (1 on NULL / empty / wl == wu) and otherwise reports failure (1) WITHOUT touching the filter. */
-EXPORT int pzg_to_RTIIRFilter(RTIIRFilter *rtif, double complex *poles, size_t N, double complex *zeros,
-                              size_t M, double gain, double wl, double wu);
+/* pzg_to_RTIIRFilter is declared in RTFilter.h, where the reference has it (ref: include/RTFilter.h:180-181). */
 #endif
 
 /* The same without complex types in the signature: gain = |H|, phase = arg H in [-pi, pi]

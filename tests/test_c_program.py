@@ -86,3 +86,61 @@ def test_c_caller_against_this_header(tmp_path):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/include"), reason="reference tree only in the build container")
 def test_c_caller_against_the_reference_header(tmp_path):
     _check(_build_and_run(tmp_path, "/root/reference/include"))
+
+
+ACCESSOR_PROGRAM = r"""
+#include <stdio.h>
+#include <RTFilter.h>
+#include <RTFilter_.h>
+#include <dsputils.h>
+
+int main(void)
+{
+    double b[3] = {0.2, 0.3, 0.1}, a[2] = {1.0, -0.5};
+    RTIIRFilter *f = RTIIRFilter_new(a, 2, b, 3, 0, NULL);
+    if (!f) return 2;
+    printf("%zu %zu %a %a %d\n", RTIIRFilter_get_b_size(f), RTIIRFilter_get_a_size(f), RTIIRFilter_get_b(f)[2],
+           RTIIRFilter_get_a(f)[1], (int)(RTIIRFilter_get_a(f) - RTIIRFilter_get_b(f)));
+    printf("%zu %a %zu\n", IIRFilterBank_get_a_size(&f->ifb), IIRFilterBank_get_b(&f->ifb)[0], FIR_order(&f->ifb.fb));
+    RTFilter_del((RTFilter *)f);
+    double bf[2] = {0.5, 0.5};
+    RTFIRFilter *g = RTFIRFilter_new(bf, 2, 0, NULL);
+    if (!g) return 3;
+    printf("%zu %a %zu\n", RTFIRFilter_get_b_size(g), RTFIRFilter_get_b(g)[1], FilterBank_get_b_size(&g->fb));
+    RTFilter_del((RTFilter *)g);
+    printf("%a %a %a %a\n", passband_ripple_epsilon_to_db(0.5), passband_ripple_db_to_epsilon(1.0),
+           stopband_ripple_epsilon_to_db(0.1), stopband_ripple_db_to_epsilon(40.0));
+    return 0;
+}
+"""
+
+
+def _run_accessors(tmp_path, include_dir):
+    global PROGRAM
+    keep = PROGRAM
+    try:
+        PROGRAM = ACCESSOR_PROGRAM
+        return _build_and_run(tmp_path, include_dir)
+    finally:
+        PROGRAM = keep
+
+
+def test_accessor_header_of_this_library(tmp_path):
+    """include/RTFilter_.h and include/dsputils.h (ref: include/RTFilter_.h:8-71, include/dsputils.h:1-12)."""
+    lines = _run_accessors(tmp_path, os.path.join(ROOT, "include"))
+    def parse(line):
+        return [float.fromhex(t) if "x" in t else int(t) for t in line.split()]
+    assert parse(lines[0]) == [3, 2, 0.1, -0.5, 3]
+    assert parse(lines[1]) == [2, 0.2, 3]
+    assert parse(lines[2]) == [2, 0.5, 2]
+    vals = [float.fromhex(v) for v in lines[3].split()]
+    assert abs(vals[0] - 0.9691001300805642) < 1e-15 and abs(vals[1] - 0.5088471399095875) < 1e-15
+    assert abs(vals[2] - 20.043213737826427) < 1e-13 and abs(vals[3] - 0.010000500037503126) < 1e-16
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include"), reason="reference tree only in the build container")
+def test_accessor_header_matches_the_reference_header(tmp_path):
+    mine = _run_accessors(tmp_path, os.path.join(ROOT, "include"))
+    (tmp_path / "ref").mkdir()
+    theirs = _run_accessors(tmp_path / "ref", "/root/reference/include")
+    assert mine == theirs

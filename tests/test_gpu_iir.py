@@ -256,3 +256,29 @@ def test_pool_reuses_blocks(G):
     assert dspdll.dsp_pool_free(p2) == 0
     assert dspdll.dsp_pool_free(C.c_void_p(12345)) != 0      # foreign pointer rejected
     assert dspdll.dsp_pool_trim(0) == 0
+
+
+def test_pool_free_async_is_stream_ordered(G):
+    """dsp_pool_free_async: the block is cached at once but not handed out again while work enqueued on the
+    freeing stream before the free is still running."""
+    import ctypes as C
+    import torch
+    from dsp_amd.cdsp import dspdll
+    size = 5 << 20
+    p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert dspdll.dsp_pool_trim(0) == 0
+    assert dspdll.dsp_pool_alloc(C.byref(p1), size, 0) == 0
+    big = torch.empty((64, 1 << 22), dtype=torch.float64, device="cuda")        # 2 GiB
+    s = torch.cuda.Stream()
+    sp = C.c_void_p(s.cuda_stream)
+    for _ in range(40):                                   # tens of milliseconds of queued work on s
+        assert dspdll.dsp_synth_fill(C.c_void_p(big.data_ptr()), 1 << 22, 64, 1 << 22, 1, 0, 0, sp) == 0
+    assert dspdll.dsp_pool_free_async(p1, sp) == 0
+    assert dspdll.dsp_pool_bytes_cached(0) >= size
+    assert dspdll.dsp_pool_alloc(C.byref(p2), size, 0) == 0
+    assert p2.value != p1.value, "block handed out while its free was still pending on the stream"
+    s.synchronize()
+    assert dspdll.dsp_pool_alloc(C.byref(p3), size, 0) == 0
+    assert p3.value == p1.value                            # reusable once the stream has passed the free
+    assert dspdll.dsp_pool_free(p2) == 0 and dspdll.dsp_pool_free(p3) == 0
+    assert dspdll.dsp_pool_trim(0) == 0

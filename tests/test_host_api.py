@@ -205,3 +205,35 @@ def test_device_api_fails_loudly_without_a_gpu():
     with pytest.raises(gbank.DSPError) as ei:
         gstream.FilterStream(gbank.iir_design(b, a))
     assert ei.value.status == cdsp.RTFB_EDEVICE
+
+
+def test_bank_table_size_check_is_host_only():
+    """dsp_bank_table_doubles: the 32-bit table-offset limit of the kernels is checked on the host before a bank is
+    built (no device needed): a bank of 500 000 distinct order-16 designs is refused with RTFB_ESIZE."""
+    import ctypes as C
+    import numpy as np
+    from dsp_amd import cdsp
+    b = np.ones(17)
+    a = np.ones(17)
+
+    def designs(n, taps):
+        arr = (cdsp.RTFilterDesign_ * n)()
+        for i in range(n):
+            arr[i].kind = cdsp.RTFB_KIND_IIR
+            arr[i].nb = taps
+            arr[i].na = taps
+            arr[i].b = b.ctypes.data_as(C.POINTER(C.c_double))
+            arr[i].a = a.ctypes.data_as(C.POINTER(C.c_double))
+        return arr
+
+    out = C.c_size_t()
+    # one order-8 design: A^(64 2^k) 6x64 + G64 65x8 + A^(32 2^k) 7x64 + G32 33x8 + 64 row propagators of 64
+    assert cdsp.dspdll.dsp_bank_table_doubles(designs(1, 9), 1, C.byref(out)) == cdsp.RTFB_OK
+    assert out.value == 6 * 64 + 65 * 8 + 7 * 64 + 33 * 8 + 64 * 64
+    # more than 1024 designs: no row propagators
+    assert cdsp.dspdll.dsp_bank_table_doubles(designs(2000, 9), 2000, C.byref(out)) == cdsp.RTFB_OK
+    assert out.value == 2000 * (6 * 64 + 65 * 8 + 7 * 64 + 33 * 8)
+    n = 500_000
+    assert cdsp.dspdll.dsp_bank_table_doubles(designs(n, 17), n, C.byref(out)) == cdsp.RTFB_ESIZE
+    assert out.value == n * (6 * 256 + 65 * 16 + 7 * 256 + 33 * 16) > 2 ** 31
+    assert b"2^31" in cdsp.dspdll.RTFilterBank_last_error()

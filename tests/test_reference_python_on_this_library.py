@@ -40,6 +40,11 @@ def test_reference_python_layer_runs_on_this_library(tmp_path):
     env = dict(os.environ)
     libdir = os.path.join(ROOT, "dsp_amd", "lib")
     env["LD_LIBRARY_PATH"] = os.pathsep.join([libdir, "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    # The reference tree ships a __pycache__ with byte code built by its authors; Python would load it instead of
+    # compiling the .py sources.  A private cache prefix makes the child ignore that directory for reading and
+    # writing: only source text of the reference is ever executed here.
+    env["PYTHONPYCACHEPREFIX"] = str(tmp_path / "pycache")
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
     r = subprocess.run([sys.executable, "-c", RUNNER, REF_PY, str(inp), str(out)], env=env, cwd=str(tmp_path),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
