@@ -166,11 +166,10 @@ def main():
     if args.jitter:
         from dsp_amd import dsp
         rng = np.random.default_rng(SEED + rank)
-        designs = []
-        for c in range(CHANNELS):
-            wl = 0.25 + 0.1 * rng.random()
-            f = dsp.butterworth(4, wl, wl + 0.25 + 0.05 * rng.random())
-            designs.append(gbank.iir_design(np.array(f.b()), np.array(f.a())))
+        wl = 0.25 + 0.1 * rng.random(CHANNELS)
+        wu = wl + 0.25 + 0.05 * rng.random(CHANNELS)
+        jb, ja, _ = dsp.design_batch("butterworth", 4, wl, wu)       # host threads, bits of dsp.butterworth
+        designs = [gbank.iir_design(jb[c], ja[c]) for c in range(CHANNELS)]
         bank = gbank.FilterBank(designs, list(range(CHANNELS)), device=local, mode=mode)
     else:
         bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)

@@ -14,7 +14,8 @@ import numpy as np
 from . import cdsp
 from .cdsp import dspdll
 
-KIND_IIR, KIND_FIR, KIND_FIR_PARTIAL = cdsp.RTFB_KIND_IIR, cdsp.RTFB_KIND_FIR, cdsp.RTFB_KIND_FIR_PARTIAL
+KIND_IIR, KIND_FIR, KIND_FIR_PARTIAL, KIND_SOS = (cdsp.RTFB_KIND_IIR, cdsp.RTFB_KIND_FIR, cdsp.RTFB_KIND_FIR_PARTIAL,
+                                                   cdsp.RTFB_KIND_SOS)
 MODE_AUTO, MODE_SEQUENTIAL, MODE_SCAN = cdsp.RTFB_MODE_AUTO, cdsp.RTFB_MODE_SEQUENTIAL, cdsp.RTFB_MODE_SCAN
 
 
@@ -59,6 +60,14 @@ def iir_design(b, a):
                 a=np.ascontiguousarray(a, dtype=np.float64))
 
 
+def sos_design(sections):
+    """sections: [(b, a), ...] with three taps each (dsp.design_sos, RTIIRFilter.sections())."""
+    b = np.ascontiguousarray([t for sb, _ in sections for t in sb], dtype=np.float64)
+    a = np.ascontiguousarray([t for _, sa in sections for t in sa], dtype=np.float64)
+    assert len(b) == len(a) == 3 * len(sections)
+    return dict(kind=KIND_SOS, b=b, a=a)
+
+
 def fir_design(b, partial=False):
     return dict(kind=KIND_FIR_PARTIAL if partial else KIND_FIR,
                 b=np.ascontiguousarray(b, dtype=np.float64), a=None)
@@ -76,7 +85,7 @@ class FilterBank:
             arr[i].kind = d["kind"]
             arr[i].nb = len(d["b"])
             arr[i].b = d["b"].ctypes.data_as(C.POINTER(C.c_double))
-            if d["kind"] == KIND_IIR:
+            if d["kind"] in (KIND_IIR, KIND_SOS):
                 arr[i].na = len(d["a"])
                 arr[i].a = d["a"].ctypes.data_as(C.POINTER(C.c_double))
         idx = np.ascontiguousarray(design_of_channel, dtype=np.int32)

@@ -136,9 +136,28 @@ _proto("RTFIRFilter_print", None, [POINTER(RTFIRFilter_)])
 _proto("filter_response_pzg_noc", c_int, [_dp, _dp, c_size_t, _dp, _dp, c_size_t, _dp, _dp, c_size_t, c_double, _dp])
 _proto("filter_response_ab_noc", c_int, [_dp, _dp, c_size_t, _dp, c_size_t, _dp, c_size_t, _dp])
 
+# ---- include/RTFilterDesign.h (additive host design entry points) ---------------------------------
+FILTER_FINITE, FILTER_SOS = 0x1, 0x2
+DSP_FAMILY_BUTTERWORTH, DSP_FAMILY_CHEBYSHEV1, DSP_FAMILY_CHEBYSHEV2 = 0, 1, 2
+DSP_WINDOW_RECTANGULAR, DSP_WINDOW_HAMMING, DSP_WINDOW_HANN, DSP_WINDOW_BLACKMAN = 0, 1, 2, 3
+DSP_MAX_SECTIONS = 64
+
+
+class RTFilterSection_(Structure):
+    _fields_ = [("b", c_double * 3), ("a", c_double * 3)]
+
+
+_proto("dsp_design_sos", c_int, [c_int, c_size_t, c_double, c_double, c_double, POINTER(RTFilterSection_), c_size_t,
+                                 POINTER(c_size_t)])
+_proto("RTIIRFilter_sos_sections", c_int, [POINTER(RTIIRFilter_), POINTER(RTFilterSection_), c_size_t,
+                                           POINTER(c_size_t)])
+_proto("dsp_design_batch", c_int, [c_int, c_size_t, c_size_t, _dp, _dp, _dp, _dp, _dp, c_size_t, POINTER(c_size_t),
+                                   c_int])
+_proto("fir_windowed_sinc", c_int, [POINTER(RTFIRFilter_), c_size_t, c_double, c_double, c_int, _cb])
+
 # ---- include/RTFilterBank.h -------------------------------------------------------------------
 RTFB_OK, RTFB_EINVAL, RTFB_ESIZE, RTFB_EUNSUPPORTED, RTFB_EDEVICE, RTFB_ENOMEM = range(6)
-RTFB_KIND_IIR, RTFB_KIND_FIR, RTFB_KIND_FIR_PARTIAL = 0, 1, 2
+RTFB_KIND_IIR, RTFB_KIND_FIR, RTFB_KIND_FIR_PARTIAL, RTFB_KIND_SOS = 0, 1, 2, 3
 RTFB_MODE_AUTO, RTFB_MODE_SEQUENTIAL, RTFB_MODE_SCAN = 0, 1, 2
 
 _proto("RTFilterBank_from_filters", c_int, [POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_int])

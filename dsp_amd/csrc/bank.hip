@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <atomic>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "RTFilterBank.h"
+#include "RTFilterDesign.h"
 #include "RTFilterStream.h"
 #include "dsp_internal.h"
 
@@ -262,7 +264,9 @@ struct Design {
     int gtab1_off = 0;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
     bool has_tables = false;            /* scan tables built (false: the design's group is sequential-only) */
+    std::vector<int> section_design;    /* RTFB_KIND_SOS: the IIR design (nb = na = 3) of every section */
     bool scan_safe() const;
+    /* SOS: three slots per section, laid out section after section (the third, never written, is 0) */
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
     bool fast_iir() const
     {
@@ -279,6 +283,9 @@ struct Group {
     bool has_tables = true;             /* kIirFast: every design carries its scan tables          */
     bool unit_a0 = false;               /* kIirFast: every design has a[0] == 1.0               */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
+    std::vector<int32_t> chan_design;   /* design index per entry of chans (a section's design for SOS channels) */
+    int stage = 0;                      /* SOS: which section of its channels this group runs; stage k reads the
+                                           output rows that stage k-1 wrote (in place), stage 0 the input rows */
     int state_ld = 1;
     /* device */
     int32_t *d_chan = nullptr;
@@ -581,22 +588,51 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     std::vector<int32_t> coef_off, pow_off, pow2_off, levels2, gtab_off, ttab_off, levels1, gtab1_off, nb, na, kind;
     std::vector<double> coefs, pows;
     size_t ld = 1;
+    /* RTFB_KIND_SOS designs: every section becomes an IIR design of its own (nb = na = 3) that the ordinary
+     * kernels run; the channel's sections are chained through launch groups of increasing `stage`. */
+    {
+        const size_t nd0 = bk->designs.size();
+        for (size_t i = 0; i < nd0; ++i) {
+            if (bk->designs[i].kind != RTFB_KIND_SOS) continue;
+            const int nsec = bk->designs[i].nb / 3;
+            for (int k = 0; k < nsec; ++k) {
+                Design sec;
+                sec.kind = RTFB_KIND_IIR;
+                sec.nb = sec.na = 3;
+                sec.b.assign(bk->designs[i].b.begin() + 3 * k, bk->designs[i].b.begin() + 3 * k + 3);
+                sec.a.assign(bk->designs[i].a.begin() + 3 * k, bk->designs[i].a.begin() + 3 * k + 3);
+                bk->designs[i].section_design.push_back((int)bk->designs.size());
+                bk->designs.push_back(std::move(sec));
+            }
+        }
+    }
+    /* (channel, stage) -> the design a launch group runs there */
+    auto stages_of = [&](size_t c) { const Design &d = bk->designs[bk->design_of[c]];
+                                     return d.kind == RTFB_KIND_SOS ? (int)d.section_design.size() : 1; };
+    auto stage_design = [&](size_t c, int stage) { const Design &d = bk->designs[bk->design_of[c]];
+                                                   return d.kind == RTFB_KIND_SOS ? d.section_design[stage] : bk->design_of[c]; };
     {
         /* Designs whose launch group can never take a scan kernel carry no scan tables and skip the
          * conditioning probe: orders <= 8 in a class of >= 2 * kAutoSeqMinChannels channels run the
          * lane-per-channel kernel in every mode (RTFilterBank_updaten). */
-        std::map<int, size_t> class_channels;                    /* fast-IIR class -> channels */
-        for (size_t c = 0; c < bk->nch; ++c) {
-            const Design &d = bk->designs[bk->design_of[c]];
-            if (d.fast_iir()) class_channels[2 * (d.nb - 1) + (d.a[0] == 1.0 ? 1 : 0)]++;
-        }
+        std::map<int, size_t> class_channels;                    /* fast-IIR class (per stage) -> channels */
+        auto class_of = [](const Design &d, int stage) { return 64 * stage + 2 * (d.nb - 1) + (d.a[0] == 1.0 ? 1 : 0); };
+        std::vector<int> design_stage(bk->designs.size(), 0);
+        for (size_t c = 0; c < bk->nch; ++c)
+            for (int k = 0; k < stages_of(c); ++k) {
+                const int di = stage_design(c, k);
+                const Design &d = bk->designs[di];
+                design_stage[di] = k;
+                if (d.fast_iir()) class_channels[class_of(d, k)]++;
+            }
         const bool with_ttab = bk->designs.size() <= kMaxPipeDesigns;
         size_t ncoef = 0, npow = 0;
-        for (Design &d : bk->designs) {
+        for (size_t di = 0; di < bk->designs.size(); ++di) {
+            Design &d = bk->designs[di];
             d.has_tables = false;
             if (d.fast_iir()) {
                 const int N = d.nb - 1;
-                const auto it = class_channels.find(2 * N + (d.a[0] == 1.0 ? 1 : 0));
+                const auto it = class_channels.find(class_of(d, design_stage[di]));
                 const size_t width = it == class_channels.end() ? 0 : it->second;
                 d.has_tables = width > 0 && !(N <= kScan2MaxOrder && width >= kSeqOnlyChannels);
             }
@@ -673,34 +709,44 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
     bk->state_ld = ld;
 
     /* groups */
-    std::map<std::pair<int, int>, size_t> index;
+    std::map<std::tuple<int, int, int>, size_t> index;          /* (stage, class, subkey) -> group */
     for (size_t c = 0; c < bk->nch; ++c) {
-        const Design &d = bk->designs[bk->design_of[c]];
-        std::pair<int, int> key;
-        if (d.kind != RTFB_KIND_IIR) key = {kFir, 0};
-        else if (d.fast_iir())
-            key = {kIirFast, 4 * (d.nb - 1) + (d.a[0] == 1.0 ? 2 : 0) + (d.scan_safe() ? 1 : 0)};
-        else key = {kIirGeneric, 0};
-        auto it = index.find(key);
-        if (it == index.end()) {
-            Group g;
-            g.cls = (GroupClass)key.first;
-            g.order = key.second / 4;
-            g.unit_a0 = (key.second & 2) != 0;
-            g.scan_safe = (key.second & 1) != 0;
-            it = index.emplace(key, bk->groups.size()).first;
-            bk->groups.push_back(g);
+        for (int stage = 0; stage < stages_of(c); ++stage) {
+            const int di = stage_design(c, stage);
+            const Design &d = bk->designs[di];
+            int cls, sub = 0;
+            if (d.kind != RTFB_KIND_IIR) cls = kFir;
+            else if (d.fast_iir()) {
+                cls = kIirFast;
+                sub = 4 * (d.nb - 1) + (d.a[0] == 1.0 ? 2 : 0) + (d.scan_safe() ? 1 : 0);
+            } else cls = kIirGeneric;
+            const auto key = std::make_tuple(stage, cls, sub);
+            auto it = index.find(key);
+            if (it == index.end()) {
+                Group g;
+                g.cls = (GroupClass)cls;
+                g.stage = stage;
+                g.order = sub / 4;
+                g.unit_a0 = (sub & 2) != 0;
+                g.scan_safe = (sub & 1) != 0;
+                it = index.emplace(key, bk->groups.size()).first;
+                bk->groups.push_back(g);
+            }
+            Group &g = bk->groups[it->second];
+            g.chans.push_back((int32_t)c);
+            g.chan_design.push_back(di);
+            g.state_ld = std::max(g.state_ld, d.state_slots());
+            g.levels2_max = std::max(g.levels2_max, d.levels2);
+            if (d.fast_iir() && !d.has_tables) g.has_tables = false;
+            if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
+            if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
+            if (g.single_design == -2) g.single_design = di;
+            else if (g.single_design != di) g.single_design = -1;
         }
-        Group &g = bk->groups[it->second];
-        g.chans.push_back((int32_t)c);
-        g.state_ld = std::max(g.state_ld, d.state_slots());
-        g.levels2_max = std::max(g.levels2_max, d.levels2);
-        if (d.fast_iir() && !d.has_tables) g.has_tables = false;
-        if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
-        if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
-        if (g.single_design == -2) g.single_design = bk->design_of[c];
-        else if (g.single_design != bk->design_of[c]) g.single_design = -1;
     }
+    /* launch order = stage order (the map iterates stages ascending; groups were appended in channel order) */
+    std::stable_sort(bk->groups.begin(), bk->groups.end(),
+                     [](const Group &p, const Group &q) { return p.stage < q.stage; });
 
     int rc;
     if ((rc = upload(&bk->d_coef_off, coef_off, device))) return rc;
@@ -724,12 +770,15 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         std::vector<double> st(cnt * (size_t)g.state_ld, 0.0), fv(cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const size_t c = (size_t)g.chans[i];
-            dsn[i] = bk->design_of[c];
+            dsn[i] = g.chan_design[i];
             fv[i] = init_fval.empty() ? 0.0 : init_fval[c];
             ini[i] = init_init.empty() ? FILTER_RESET : init_init[c];
             if (!init_state.empty()) {
+                /* a section of an SOS channel owns slots [3 stage, 3 stage + 3) of the channel's state row */
+                const bool sos = bk->designs[bk->design_of[c]].kind == RTFB_KIND_SOS;
                 const int slots = bk->designs[dsn[i]].state_slots();
-                for (int k = 0; k < slots; ++k) st[i * g.state_ld + k] = init_state[c * ld + k];
+                const size_t off = sos ? (size_t)3 * g.stage : 0;
+                for (int k = 0; k < slots; ++k) st[i * g.state_ld + k] = init_state[c * ld + off + k];
             }
         }
         if (!g.contiguous && (rc = upload(&g.d_chan, g.chans, device))) return rc;
@@ -787,9 +836,15 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
 
 int validate_design(const RTFilterDesign &d)
 {
-    if (d.kind != RTFB_KIND_IIR && d.kind != RTFB_KIND_FIR && d.kind != RTFB_KIND_FIR_PARTIAL)
+    if (d.kind != RTFB_KIND_IIR && d.kind != RTFB_KIND_FIR && d.kind != RTFB_KIND_FIR_PARTIAL &&
+        d.kind != RTFB_KIND_SOS)
         return fail(RTFB_EINVAL, "design.kind is not an RTFB_KIND_* value");
     if (!d.b || d.nb == 0) return fail(RTFB_EINVAL, "design needs at least one b tap");
+    if (d.kind == RTFB_KIND_SOS) {
+        if (!d.a || d.na != d.nb || d.nb % 3 || d.nb / 3 > (size_t)DSP_MAX_SECTIONS)
+            return fail(RTFB_EINVAL, "SOS design: b and a hold three taps per section, at most 64 sections");
+        return RTFB_OK;
+    }
     if (d.kind == RTFB_KIND_IIR) {
         if (!d.a || d.na == 0) return fail(RTFB_EINVAL, "IIR design needs at least one a tap");
         if (d.nb > (size_t)kMaxGenericTaps || d.na > (size_t)kMaxGenericTaps)
@@ -923,7 +978,7 @@ int dsp_scan_probe(const RTFilterDesign *design, double *rel_error)
     Design d;
     d.kind = design->kind;
     d.nb = (int)design->nb;
-    d.na = d.kind == RTFB_KIND_IIR ? (int)design->na : 0;
+    d.na = (d.kind == RTFB_KIND_IIR || d.kind == RTFB_KIND_SOS) ? (int)design->na : 0;
     d.b.assign(design->b, design->b + d.nb);
     if (d.na) d.a.assign(design->a, design->a + d.na);
     if (!d.fast_iir()) return fail(RTFB_EUNSUPPORTED, "the scan kernel takes IIR designs with na == nb <= 17");
@@ -946,7 +1001,7 @@ int dsp_bank_table_doubles(const RTFilterDesign *designs, size_t ndesign, size_t
         Design d;
         d.kind = designs[i].kind;
         d.nb = (int)designs[i].nb;
-        d.na = d.kind == RTFB_KIND_IIR ? (int)designs[i].na : 0;
+        d.na = (d.kind == RTFB_KIND_IIR || d.kind == RTFB_KIND_SOS) ? (int)designs[i].na : 0;
         d.has_tables = d.fast_iir();
         total += design_table_doubles(d, ndesign <= kMaxPipeDesigns);
         ncoef += (size_t)d.nb + (size_t)d.na;
@@ -974,7 +1029,7 @@ int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *designs
         Design d;
         d.kind = designs[i].kind;
         d.nb = (int)designs[i].nb;
-        d.na = d.kind == RTFB_KIND_IIR ? (int)designs[i].na : 0;
+        d.na = (d.kind == RTFB_KIND_IIR || d.kind == RTFB_KIND_SOS) ? (int)designs[i].na : 0;
         d.b.assign(designs[i].b, designs[i].b + d.nb);
         if (d.na) d.a.assign(designs[i].a, designs[i].a + d.na);
         bk->designs.push_back(std::move(d));
@@ -1011,6 +1066,7 @@ int RTFilterBank_from_filters(RTFilterBank **bank, RTFilter *const *filters, siz
     bk->host_filters.assign(filters, filters + nch);
     std::map<std::string, int> seen;            /* coefficient bytes -> design index */
     std::vector<const double *> st_ptr(nch);
+    std::deque<std::vector<double>> sos_taps;   /* unpacked sections of FILTER_SOS filters (stable addresses) */
     size_t ld = 1;
     for (size_t c = 0; c < nch; ++c) {
         RTFilter *f = filters[c];
@@ -1025,6 +1081,26 @@ int RTFilterBank_from_filters(RTFilterBank **bank, RTFilter *const *filters, siz
             rd.na = q->ifb.na;
             rd.b = q->ifb.fb.b;
             rd.a = q->ifb.fb.b + q->ifb.fb.nb;
+            st_ptr[c] = q->state;
+        } else if (f->update == RTIIRFilter_sos_update && f->initialize == RTIIRFilter_sos_stable_init) {
+            RTIIRFilter *q = reinterpret_cast<RTIIRFilter *>(f);
+            RTFilterSection sec[DSP_MAX_SECTIONS];
+            size_t ns = 0;
+            if (RTIIRFilter_sos_sections(q, sec, DSP_MAX_SECTIONS, &ns) || !ns) {
+                delete bk;
+                return fail(RTFB_EINVAL, "FILTER_SOS filter without sections");
+            }
+            sos_taps.emplace_back(6 * ns);
+            std::vector<double> &t = sos_taps.back();       /* b of all sections, then a of all sections */
+            for (size_t k = 0; k < ns; ++k)
+                for (int j = 0; j < 3; ++j) {
+                    t[3 * k + j] = sec[k].b[j];
+                    t[3 * ns + 3 * k + j] = sec[k].a[j];
+                }
+            rd.kind = RTFB_KIND_SOS;
+            rd.nb = rd.na = 3 * ns;
+            rd.b = t.data();
+            rd.a = t.data() + 3 * ns;
             st_ptr[c] = q->state;
         } else if (f->update == RTFIRFilter_update &&
                    (f->initialize == RTFIRFilter_stable_init ||
@@ -1065,8 +1141,15 @@ int RTFilterBank_from_filters(RTFilterBank **bank, RTFilter *const *filters, siz
     std::vector<double> st(nch * ld, 0.0), fv(nch);
     std::vector<int32_t> ini(nch);
     for (size_t c = 0; c < nch; ++c) {
-        const int slots = bk->designs[bk->design_of[c]].state_slots();
-        std::memcpy(&st[c * ld], st_ptr[c], slots * sizeof(double));
+        const Design &d = bk->designs[bk->design_of[c]];
+        const int slots = d.state_slots();
+        if (d.kind == RTFB_KIND_SOS) {              /* host: two doubles per section; here three (the last is 0) */
+            for (int k = 0; k < slots / 3; ++k) {
+                st[c * ld + 3 * k] = st_ptr[c][2 * k];
+                st[c * ld + 3 * k + 1] = st_ptr[c][2 * k + 1];
+            }
+        } else
+            std::memcpy(&st[c * ld], st_ptr[c], slots * sizeof(double));
         fv[c] = filters[c]->filtered_value;
         ini[c] = filters[c]->initialized;
     }
@@ -1123,8 +1206,15 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
     io.aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) &&
                    ld_in % 2 == 0 && ld_out % 2 == 0;
 
+    const BlockIO io_first = io;
     for (Group &g : bank->groups) {
         GroupView v = view_of(bank, g);
+        io = io_first;
+        if (g.stage > 0) {                   /* a later section of SOS channels filters the output rows in place */
+            io.in = out;
+            io.ld_in = ld_out;
+            io.aligned16 = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && ld_out % 2 == 0;
+        }
         if (g.cls == kFir) {
             /* FIR outputs are computed out of order in time, so the kernels must not see their
              * own outputs as inputs: an in-place call (allowed by the reference, where each
@@ -1263,6 +1353,21 @@ int RTFilterBank_get_state(RTFilterBank *bank, double *state, double *fval, int3
         HIP_TRY(hipMemcpy(ini.data(), g.d_init, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; ++i) {
             const size_t c = (size_t)g.chans[i];
+            const Design &cd = bank->designs[bank->design_of[c]];
+            if (cd.kind == RTFB_KIND_SOS) {
+                /* section `stage` owns slots [3 stage, 3 stage + 3); the last section's output is the channel's
+                 * filtered_value; every section carries the same `initialized` */
+                const size_t off = (size_t)3 * g.stage;
+                const bool last = g.stage + 1 == (int)cd.section_design.size();
+                if (state) {
+                    for (size_t k = 0; k < 3; ++k) state[c * ld + off + k] = st[i * g.state_ld + k];
+                    if (last)
+                        for (size_t k = off + 3; k < ld; ++k) state[c * ld + k] = 0.0;
+                }
+                if (fval && last) fval[c] = fv[i];
+                if (init && g.stage == 0) init[c] = ini[i];
+                continue;
+            }
             if (state) {
                 for (size_t k = 0; k < ld; ++k)
                     state[c * ld + k] = k < (size_t)g.state_ld ? st[i * g.state_ld + k] : 0.0;
@@ -1286,9 +1391,12 @@ int RTFilterBank_set_state(RTFilterBank *bank, const double *state, const double
         const size_t cnt = g.chans.size();
         if (state) {
             std::vector<double> st(cnt * (size_t)g.state_ld);
-            for (size_t i = 0; i < cnt; ++i)
+            for (size_t i = 0; i < cnt; ++i) {
+                const size_t c = (size_t)g.chans[i];
+                const size_t off = bank->designs[bank->design_of[c]].kind == RTFB_KIND_SOS ? (size_t)3 * g.stage : 0;
                 for (int k = 0; k < g.state_ld; ++k)
-                    st[i * g.state_ld + k] = state[(size_t)g.chans[i] * ld + k];
+                    st[i * g.state_ld + k] = off + k < ld ? state[c * ld + off + k] : 0.0;
+            }
             HIP_TRY(hipMemcpy(g.d_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         if (fval) {
@@ -1318,9 +1426,16 @@ int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream)
     for (size_t c = 0; c < bank->nch; ++c) {
         RTFilter *f = bank->host_filters[c];
         const Design &d = bank->designs[bank->design_of[c]];
-        double *dst = d.kind == RTFB_KIND_IIR ? reinterpret_cast<RTIIRFilter *>(f)->state
-                                              : reinterpret_cast<RTFIRFilter *>(f)->state;
-        std::memcpy(dst, &st[c * ld], d.state_slots() * sizeof(double));
+        double *dst = d.kind == RTFB_KIND_FIR || d.kind == RTFB_KIND_FIR_PARTIAL
+                          ? reinterpret_cast<RTFIRFilter *>(f)->state
+                          : reinterpret_cast<RTIIRFilter *>(f)->state;
+        if (d.kind == RTFB_KIND_SOS) {              /* the host filter keeps two doubles per section */
+            for (size_t k = 0; k < d.section_design.size(); ++k) {
+                dst[2 * k] = st[c * ld + 3 * k];
+                dst[2 * k + 1] = st[c * ld + 3 * k + 1];
+            }
+        } else
+            std::memcpy(dst, &st[c * ld], d.state_slots() * sizeof(double));
         f->filtered_value = fv[c];
         f->initialized = ini[c];
     }

@@ -24,10 +24,13 @@
  *   - the stray debug printf calls of chebyshev2 (:1384-1406) and the band-stop
  *     transform (:850) are not reproduced.
  */
+#include <complex.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 
 #include "RTFilter.h"
+#include "RTFilterDesign.h"
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -336,49 +339,80 @@ static void proto_bw(cascade *cs, size_t order, double ripple, double w0)
     prototype_butterworth(cs, order, w0);
 }
 
+static prototype_fn family_prototype(int family)
+{
+    switch (family) {
+        case DSP_FAMILY_BUTTERWORTH: return proto_bw;
+        case DSP_FAMILY_CHEBYSHEV1: return prototype_chebyshev1;
+        case DSP_FAMILY_CHEBYSHEV2: return prototype_chebyshev2;
+    }
+    return NULL;
+}
+
+/* prototype + band transform: the factored design every output form starts from */
+static int build_cascade(cascade *cs, size_t order, double ripple, double wl, double wu, prototype_fn proto)
+{
+    const double w0 = wu < wl ? wl : wu;
+    if (cascade_alloc(cs, order)) return 1;
+    proto(cs, order, ripple, w0);
+    transform_cascade(cs, w0, wl, wu);
+    return 0;
+}
+
+static size_t design_ncoef(size_t order, double wl, double wu)
+{
+    return ((wu > 0.0 && wl > 0.0) ? 2 : 1) * order + 1;
+}
+
+/* transfer-function coefficients b[0..ncoef), a[0..ncoef) of one design (the arithmetic of the reference's
+ * digital_prototype_to_IIRFilterBank, src/RTFilter.c:977-1140) */
+static int design_tf(double *b, double *a, size_t ncoef, size_t order, double ripple, double wl, double wu,
+                     prototype_fn proto)
+{
+    cascade cs;
+    if (build_cascade(&cs, order, ripple, wl, wu, proto)) return 1;
+    expand_list(b, ncoef, cs.gain, cs.zeros, cs.nzeros);
+    expand_list(a, ncoef, 1.0, cs.poles, cs.npoles);
+    cascade_free(&cs);
+    return 0;
+}
+
+static int pack_sos(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu, prototype_fn proto);
+
 static int classical_design(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu,
-                            rtf_sample_fn initialize, prototype_fn proto)
+                            unsigned int flags, rtf_sample_fn initialize, prototype_fn proto)
 {
     if (!rtif || wl == wu || !order) return 1;
-    const int two_edges = wu > 0.0 && wl > 0.0;
-    const size_t ncoef = (two_edges ? 2 : 1) * order + 1;
+    const size_t ncoef = design_ncoef(order, wl, wu);
     if (rtif->ifb.na < ncoef || rtif->ifb.fb.nb < ncoef) return 2;
+    if (flags & FILTER_SOS) return pack_sos(rtif, order, ripple, wl, wu, proto);
     if (!initialize) rtif->rtf.initialize = RTIIRFilter_stable_init;
 
-    const double w0 = wu < wl ? wl : wu;
-    cascade cs;
-    if (cascade_alloc(&cs, order)) return 1;
-    proto(&cs, order, ripple, w0);
-    transform_cascade(&cs, w0, wl, wu);
-
     double *bank = rtif->ifb.fb.b;
-    expand_list(bank, ncoef, cs.gain, cs.zeros, cs.nzeros);
-    expand_list(bank + ncoef, ncoef, 1.0, cs.poles, cs.npoles);
+    if (design_tf(bank, bank + ncoef, ncoef, order, ripple, wl, wu, proto)) return 1;
     rtif->ifb.fb.nb = ncoef;
     rtif->ifb.na = ncoef;
-    cascade_free(&cs);
     return 0;
 }
 
 int butterworth(RTIIRFilter *rtif, size_t order, double wl, double wu, unsigned int flags,
                 rtf_sample_fn initialize)
 {
-    (void)flags;                                   /* accepted, never interpreted (ref :1216) */
-    return classical_design(rtif, order, 0.0, wl, wu, initialize, proto_bw);
+    /* the reference stores `flags` and never reads them (ref :1216, :48-53); FILTER_SOS, reserved there "for
+     * second order sections execution" (include/RTFilter.h:51,64-66), selects the cascade form here */
+    return classical_design(rtif, order, 0.0, wl, wu, flags, initialize, proto_bw);
 }
 
 int chebyshev1(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu,
                unsigned int flags, rtf_sample_fn initialize)
 {
-    (void)flags;
-    return classical_design(rtif, order, ripple, wl, wu, initialize, prototype_chebyshev1);
+    return classical_design(rtif, order, ripple, wl, wu, flags, initialize, prototype_chebyshev1);
 }
 
 int chebyshev2(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu,
                unsigned int flags, rtf_sample_fn initialize)
 {
-    (void)flags;
-    return classical_design(rtif, order, ripple, wl, wu, initialize, prototype_chebyshev2);
+    return classical_design(rtif, order, ripple, wl, wu, flags, initialize, prototype_chebyshev2);
 }
 
 /* Thiran all-pole fractional-delay low-pass (ref: src/RTFilter.c:1459-1495):
@@ -403,5 +437,319 @@ int thiran(RTIIRFilter *rtif, size_t order, double tau, rtf_sample_fn initialize
         for (size_t i = 0; i < order + 1; i++) a[k] *= (2 * tau + i) / (2 * tau + k + i);
         a[k] *= binom;
     }
+    return 0;
+}
+
+/* ======================================================================== */
+/* Second-order sections (no reference behaviour)      */
+
+/* 1 + c[0] x + c[1] x^2 + c[2] x^3 + c[3] x^4  =  (1 + p[0] x + p[1] x^2)(1 + q[0] x + q[1] x^2), real factors.
+ * Roots of the reversed (monic in z = 1/x) polynomial by Durand-Kerner in long double complex, grouped into
+ * conjugate / real pairs, then the quadratic pair polished by Newton steps on the four coefficient equations. */
+static void factor_quartic(const double c[4], double p[2], double q[2])
+{
+    long double complex r[4];
+    const long double complex seed = 0.4L + 0.9L * I;
+    r[0] = 1.0L;
+    for (int k = 1; k < 4; k++) r[k] = r[k - 1] * seed;
+    for (int it = 0; it < 200; it++) {
+        long double move = 0.0L;
+        for (int k = 0; k < 4; k++) {
+            const long double complex z = r[k];
+            const long double complex f = (((z + c[0]) * z + c[1]) * z + c[2]) * z + c[3];
+            long double complex den = 1.0L;
+            for (int j = 0; j < 4; j++)
+                if (j != k) den *= z - r[j];
+            const long double complex step = f / den;
+            r[k] = z - step;
+            move += cabsl(step);
+        }
+        if (move < 1e-30L) break;
+    }
+    /* pair: the root with the largest |imag| and the root closest to its conjugate; the other two remain */
+    int i0 = 0;
+    for (int k = 1; k < 4; k++)
+        if (fabsl(cimagl(r[k])) > fabsl(cimagl(r[i0]))) i0 = k;
+    int i1 = -1;
+    for (int k = 0; k < 4; k++)
+        if (k != i0 && (i1 < 0 || cabsl(r[k] - conjl(r[i0])) < cabsl(r[i1] - conjl(r[i0])))) i1 = k;
+    int rest[2], nr = 0;
+    for (int k = 0; k < 4; k++)
+        if (k != i0 && k != i1) rest[nr++] = k;
+    /* (z - u)(z - v) = z^2 - (u+v) z + u v   <=>   1 - (u+v) x + u v x^2 */
+    long double P0 = -creall(r[i0] + r[i1]), P1 = creall(r[i0] * r[i1]);
+    long double Q0 = -creall(r[rest[0]] + r[rest[1]]), Q1 = creall(r[rest[0]] * r[rest[1]]);
+    /* polish: solve  P0+Q0 = c0, P1+Q1+P0 Q0 = c1, P0 Q1+P1 Q0 = c2, P1 Q1 = c3  by Newton (4x4, Gauss) */
+    for (int it = 0; it < 4; it++) {
+        long double F[4] = {P0 + Q0 - c[0], P1 + Q1 + P0 * Q0 - c[1], P0 * Q1 + P1 * Q0 - c[2], P1 * Q1 - c[3]};
+        long double J[4][5] = {{1, 0, 1, 0, -F[0]}, {Q0, 1, P0, 1, -F[1]}, {Q1, Q0, P1, P0, -F[2]}, {0, Q1, 0, P1, -F[3]}};
+        int ok = 1;
+        for (int col = 0; col < 4 && ok; col++) {
+            int piv = col;
+            for (int row = col + 1; row < 4; row++)
+                if (fabsl(J[row][col]) > fabsl(J[piv][col])) piv = row;
+            if (fabsl(J[piv][col]) < 1e-300L) { ok = 0; break; }
+            for (int k = 0; k < 5; k++) { long double t = J[col][k]; J[col][k] = J[piv][k]; J[piv][k] = t; }
+            for (int row = 0; row < 4; row++) {
+                if (row == col) continue;
+                const long double m = J[row][col] / J[col][col];
+                for (int k = col; k < 5; k++) J[row][k] -= m * J[col][k];
+            }
+        }
+        if (!ok) break;
+        P0 += J[0][4] / J[0][0];
+        P1 += J[1][4] / J[1][1];
+        Q0 += J[2][4] / J[2][2];
+        Q1 += J[3][4] / J[3][3];
+    }
+    p[0] = (double)P0; p[1] = (double)P1;
+    q[0] = (double)Q0; q[1] = (double)Q1;
+}
+
+/* A list of cascade sections (degrees 1, 2, 4) as quadratic factors 1 + f[0] x + f[1] x^2 plus at most one
+ * leftover linear factor (f[1] == 0), linear factors multiplied in pairs.  Returns the factor count. */
+static size_t quadratic_factors(const section *list, size_t count, double (*f)[2])
+{
+    size_t n = 0;
+    int have_lin = 0;
+    double lin = 0.0;
+    for (size_t i = 0; i < count; i++) {
+        const section *s = &list[i];
+        if (s->deg == 1) {
+            if (have_lin) {
+                f[n][0] = lin + s->c[0];
+                f[n][1] = lin * s->c[0];
+                n++;
+                have_lin = 0;
+            } else {
+                lin = s->c[0];
+                have_lin = 1;
+            }
+        } else if (s->deg == 2) {
+            f[n][0] = s->c[0];
+            f[n][1] = s->c[1];
+            n++;
+        } else {
+            factor_quartic(s->c, f[n], f[n + 1]);
+            n += 2;
+        }
+    }
+    if (have_lin) {
+        f[n][0] = lin;
+        f[n][1] = 0.0;
+        n++;
+    }
+    return n;
+}
+
+static int design_sos(RTFilterSection *out, size_t max_sections, size_t *nsections, size_t order, double ripple,
+                      double wl, double wu, prototype_fn proto)
+{
+    cascade cs;
+    if (build_cascade(&cs, order, ripple, wl, wu, proto)) return 1;
+    const size_t cap = 2 * order + 2;
+    double (*num)[2] = (double (*)[2])DSP_MALLOC(sizeof(double[2]) * cap);
+    double (*den)[2] = (double (*)[2])DSP_MALLOC(sizeof(double[2]) * cap);
+    int rc = 0;
+    if (!num || !den) rc = 1;
+    if (!rc) {
+        const size_t nn = quadratic_factors(cs.zeros, cs.nzeros, num);
+        const size_t nd = quadratic_factors(cs.poles, cs.npoles, den);
+        const size_t ns = nn > nd ? nn : nd;
+        if (nsections) *nsections = ns;
+        if (ns > max_sections) rc = 2;
+        for (size_t k = 0; k < ns && !rc; k++) {
+            const double g = k == 0 ? cs.gain : 1.0;                 /* the design's gain rides on section 0 */
+            out[k].b[0] = g;
+            out[k].b[1] = k < nn ? g * num[k][0] : 0.0;
+            out[k].b[2] = k < nn ? g * num[k][1] : 0.0;
+            out[k].a[0] = 1.0;
+            out[k].a[1] = k < nd ? den[k][0] : 0.0;
+            out[k].a[2] = k < nd ? den[k][1] : 0.0;
+        }
+    }
+    DSP_FREE(num);
+    DSP_FREE(den);
+    cascade_free(&cs);
+    return rc;
+}
+
+int dsp_design_sos(int family, size_t order, double ripple, double wl, double wu, RTFilterSection *sections,
+                   size_t max_sections, size_t *nsections)
+{
+    prototype_fn proto = family_prototype(family);
+    if (!proto || !order || wl == wu || (!sections && max_sections)) return 1;
+    return design_sos(sections, max_sections, nsections, order, ripple, wl, wu, proto);
+}
+
+/* FILTER_SOS on a host filter: the sections are packed into the filter's own bank (which the reference sizes
+ * for the transfer function: 2 ncoef doubles) as  g | n1' n2' d1 d2 | n1 n2 d1 d2 | ...  (section 0's numerator
+ * pre-multiplied by the gain g; a first-order last section takes two doubles: n1 d1), nb = number of sections,
+ * na = 1 if the last section is stored short, else 0; two state doubles per section.  The callbacks
+ * become RTIIRFilter_sos_update / RTIIRFilter_sos_stable_init (rtfilter_host.c). */
+static int pack_sos(RTIIRFilter *rtif, size_t order, double ripple, double wl, double wu, prototype_fn proto)
+{
+    const size_t room = rtif->ifb.fb.nb + rtif->ifb.na;
+    RTFilterSection sec[DSP_MAX_SECTIONS];
+    size_t ns = 0;
+    int rc = design_sos(sec, DSP_MAX_SECTIONS, &ns, order, ripple, wl, wu, proto);
+    if (rc) return rc;
+    const int short_last = sec[ns - 1].b[2] == 0.0 && sec[ns - 1].a[2] == 0.0;   /* first-order: two doubles */
+    if (1 + 4 * ns - (short_last ? 2 : 0) > room) return 2;
+    double *bank = rtif->ifb.fb.b;
+    bank[0] = sec[0].b[0];
+    for (size_t k = 0; k < ns; k++) {
+        double *p = bank + 1 + 4 * k;
+        if (short_last && k + 1 == ns) {
+            p[0] = sec[k].b[1];
+            p[1] = sec[k].a[1];
+        } else {
+            p[0] = sec[k].b[1];
+            p[1] = sec[k].b[2];
+            p[2] = sec[k].a[1];
+            p[3] = sec[k].a[2];
+        }
+    }
+    rtif->ifb.fb.nb = ns;
+    rtif->ifb.na = (size_t)short_last;
+    rtif->rtf.flags |= FILTER_SOS;
+    rtif->rtf.update = RTIIRFilter_sos_update;
+    rtif->rtf.initialize = RTIIRFilter_sos_stable_init;
+    for (size_t i = 0; i < 2 * ns; i++) rtif->state[i] = 0.0;
+    RTFilter_reset(&rtif->rtf);
+    return 0;
+}
+
+/* ======================================================================== */
+/* Many designs at once: the same arithmetic as the    */
+/* per-filter routines, one design per work item, over host threads           */
+
+typedef struct batch_job {
+    prototype_fn proto;
+    size_t n, order, ld;
+    const double *ripple, *wl, *wu;
+    double *b, *a;
+    size_t *ncoef;
+    size_t next;                /* shared cursor, advanced in chunks under the mutex */
+    int status;
+    pthread_mutex_t mu;
+} batch_job;
+
+static void *batch_worker(void *arg)
+{
+    batch_job *job = (batch_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        const size_t lo = job->next;
+        const size_t hi = lo + 64 < job->n ? lo + 64 : job->n;
+        job->next = hi;
+        pthread_mutex_unlock(&job->mu);
+        if (lo >= hi) break;
+        for (size_t i = lo; i < hi; i++) {
+            const double wl = job->wl ? job->wl[i] : 0.0, wu = job->wu ? job->wu[i] : 0.0;
+            const double rip = job->ripple ? job->ripple[i] : 0.0;
+            const size_t nc = design_ncoef(job->order, wl, wu);
+            int rc = (wl == wu || nc > job->ld) ? (wl == wu ? 1 : 2)
+                                                : design_tf(job->b + i * job->ld, job->a + i * job->ld, nc, job->order,
+                                                            rip, wl, wu, job->proto);
+            if (job->ncoef) job->ncoef[i] = rc ? 0 : nc;
+            if (rc) {
+                pthread_mutex_lock(&job->mu);
+                if (!job->status) job->status = rc;
+                pthread_mutex_unlock(&job->mu);
+            }
+        }
+    }
+    return NULL;
+}
+
+int dsp_design_batch(int family, size_t n, size_t order, const double *ripple, const double *wl, const double *wu,
+                     double *b, double *a, size_t ld, size_t *ncoef, int threads)
+{
+    prototype_fn proto = family_prototype(family);
+    if (!proto || !order || !b || !a || (!wl && !wu)) return 1;
+    if (family != DSP_FAMILY_BUTTERWORTH && !ripple) return 1;
+    if (!n) return 0;
+    batch_job job;
+    job.proto = proto;
+    job.n = n; job.order = order; job.ld = ld;
+    job.ripple = ripple; job.wl = wl; job.wu = wu;
+    job.b = b; job.a = a; job.ncoef = ncoef;
+    job.next = 0;
+    job.status = 0;
+    pthread_mutex_init(&job.mu, NULL);
+    if (threads <= 0) threads = 16;
+    if ((size_t)threads > (n + 63) / 64) threads = (int)((n + 63) / 64);
+    if (threads > 64) threads = 64;
+    pthread_t tid[64];
+    int started = 0;
+    for (int t = 1; t < threads; t++)
+        if (pthread_create(&tid[started], NULL, batch_worker, &job) == 0) started++;
+    batch_worker(&job);
+    for (int t = 0; t < started; t++) pthread_join(tid[t], NULL);
+    pthread_mutex_destroy(&job.mu);
+    return job.status;
+}
+
+/* ======================================================================== */
+/* FIR design (the reference has only moving_average, src/RTFilter.c:569-585)  */
+
+static double window_value(int window, size_t k, size_t taps)
+{
+    if (taps < 2) return 1.0;
+    const double t = 2.0 * M_PI * (double)k / (double)(taps - 1);
+    switch (window) {
+        case DSP_WINDOW_HAMMING: return 0.54 - 0.46 * cos(t);
+        case DSP_WINDOW_HANN: return 0.5 - 0.5 * cos(t);
+        case DSP_WINDOW_BLACKMAN: return 0.42 - 0.5 * cos(t) + 0.08 * cos(2.0 * t);
+    }
+    return 1.0;                                           /* rectangular */
+}
+
+static double sinc_pi(double x)                            /* sin(pi x) / (pi x) */
+{
+    if (x == 0.0) return 1.0;
+    const double px = M_PI * x;
+    return sin(px) / px;
+}
+
+/* Windowed-sinc FIR: ideal response of the band [wl, wu] (units of Nyquist, the conventions of butterworth:
+ * wl <= 0 low-pass at wu, wu <= 0 high-pass at wl, wl < wu band-pass, wl > wu band-stop), truncated to `taps`
+ * and shaped by `window`; the low-pass / band-stop forms are normalised to unit gain at DC (sum b = 1, which
+ * RTFIRFilter_stable_init assumes, src/RTFilter.c:250-265), band-pass to unit gain at the band centre,
+ * high-pass at Nyquist.  Writes b[0..taps) into the filter's bank and shrinks nb, like moving_average. */
+int fir_windowed_sinc(RTFIRFilter *rtff, size_t taps, double wl, double wu, int window, rtf_sample_fn initialize)
+{
+    if (!rtff || !taps || wl == wu) return 1;
+    if (window < DSP_WINDOW_RECTANGULAR || window > DSP_WINDOW_BLACKMAN) return 1;
+    if (rtff->fb.nb < taps) return 2;
+    const int lowpass = wl <= 0.0, highpass = !lowpass && wu <= 0.0, stop = !lowpass && !highpass && wl > wu;
+    if ((highpass || stop) && !(taps & 1)) return 1;      /* a type II filter has a zero at Nyquist */
+    if (!initialize) rtff->rtf.initialize = RTFIRFilter_stable_init;
+    double *b = rtff->fb.b;
+    const double m = ((double)taps - 1.0) / 2.0;
+    const double lo = stop ? wu : wl, hi = stop ? wl : wu;
+    for (size_t k = 0; k < taps; k++) {
+        const double t = (double)k - m;
+        double h;
+        if (lowpass) h = wu * sinc_pi(wu * t);
+        else if (highpass) h = sinc_pi(t) - wl * sinc_pi(wl * t);
+        else {
+            h = hi * sinc_pi(hi * t) - lo * sinc_pi(lo * t);
+            if (stop) h = sinc_pi(t) - h;
+        }
+        b[k] = h * window_value(window, k, taps);
+    }
+    /* normalise at the reference frequency of the form */
+    const double wref = (lowpass || stop) ? 0.0 : (highpass ? 1.0 : 0.5 * (wl + wu));
+    double re = 0.0, im = 0.0;
+    for (size_t k = 0; k < taps; k++) {
+        re += b[k] * cos(M_PI * wref * ((double)k - m));
+        im += b[k] * sin(M_PI * wref * ((double)k - m));
+    }
+    const double mag = sqrt(re * re + im * im);
+    if (!(mag > 0.0)) return 1;
+    for (size_t k = 0; k < taps; k++) b[k] /= mag;
+    rtff->fb.nb = taps;
     return 0;
 }

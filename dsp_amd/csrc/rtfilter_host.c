@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "RTFilter.h"
+#include "RTFilterDesign.h"
 
 /* ------------------------------------------------------------------------ */
 /* arithmetic leaves (shared by the callback entry points and the fused loop) */
@@ -430,5 +431,79 @@ int moving_average(RTFIRFilter *rtff, size_t window, rtf_sample_fn initialize)
     for (size_t i = 0; i < window; i++) w[i] = 1.0 / window;
     RTFIRFilter_init(rtff, w, rtff->state, window, 0,
                      initialize ? initialize : RTFIRFilter_partial_init);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* FILTER_SOS: a cascade of second-order sections held in an RTIIRFilter     */
+/* (include/RTFilterDesign.h; the reference reserves the flag,               */
+/* include/RTFilter.h:51,64-66, and never reads it)                          */
+
+/* Packed bank: g | n1' n2' d1 d2 | n1 n2 d1 d2 | ... [| n1 d1]; section k as the arrays an RTIIRFilter would
+ * hold.  `short_last` (the struct's na field): the last section is first-order and stored as two doubles. */
+static inline void sos_unpack(const double *bank, size_t k, size_t ns, size_t short_last, double b[3], double a[3])
+{
+    const double *p = bank + 1 + 4 * k;
+    b[0] = k == 0 ? bank[0] : 1.0;
+    a[0] = 1.0;
+    if (short_last && k + 1 == ns) {
+        b[1] = p[0]; b[2] = 0.0;
+        a[1] = p[1]; a[2] = 0.0;
+    } else {
+        b[1] = p[0]; b[2] = p[1];
+        a[1] = p[2]; a[2] = p[3];
+    }
+}
+
+/* Every section is RTIIRFilter_update with nb = na = 3 (ref: src/RTFilter.c:396-439); its never-written third
+ * state slot is the constant 0.0, kept as an operand so that signed zeros come out as they would there. */
+int RTIIRFilter_sos_update(RTFilter *rtf, double sample)
+{
+    RTIIRFilter *f = (RTIIRFilter *)rtf;
+    const double *bank = f->ifb.fb.b;
+    const size_t ns = f->ifb.fb.nb;
+    double x = sample;
+    for (size_t k = 0; k < ns; k++) {
+        double b[3], a[3], s[3];
+        sos_unpack(bank, k, ns, f->ifb.na, b, a);
+        s[0] = f->state[2 * k];
+        s[1] = f->state[2 * k + 1];
+        s[2] = 0.0;
+        x = iir_advance(b, 3, a, 3, s, x);
+        f->state[2 * k] = s[0];
+        f->state[2 * k + 1] = s[1];
+    }
+    rtf->filtered_value = x;
+    return 0;
+}
+
+/* First sample: every section is seeded by RTIIRFilter_stable_init's rule (ref: src/RTFilter.c:441-475) on the
+ * sample it sees, i.e. on the seeded output of the section before it. */
+int RTIIRFilter_sos_stable_init(RTFilter *rtf, double sample)
+{
+    RTIIRFilter *f = (RTIIRFilter *)rtf;
+    const double *bank = f->ifb.fb.b;
+    const size_t ns = f->ifb.fb.nb;
+    double x = sample;
+    for (size_t k = 0; k < ns; k++) {
+        double b[3], a[3], s[3];
+        sos_unpack(bank, k, ns, f->ifb.na, b, a);
+        x = iir_seed(b, 3, a, 3, s, x);
+        f->state[2 * k] = s[0];
+        f->state[2 * k + 1] = s[1];
+    }
+    rtf->filtered_value = x;
+    rtf->initialized = FILTER_INITIALIZED;
+    return 0;
+}
+
+int RTIIRFilter_sos_sections(const RTIIRFilter *rtif, RTFilterSection *sections, size_t max_sections,
+                             size_t *nsections)
+{
+    if (!rtif || rtif->rtf.update != RTIIRFilter_sos_update) return 1;
+    const size_t ns = rtif->ifb.fb.nb;
+    if (nsections) *nsections = ns;
+    if (ns > max_sections || (!sections && ns)) return 2;
+    for (size_t k = 0; k < ns; k++) sos_unpack(rtif->ifb.fb.b, k, ns, rtif->ifb.na, sections[k].b, sections[k].a);
     return 0;
 }

@@ -12,7 +12,7 @@ Known reference bugs are NOT reproduced: chebyshev1/2 pass `ripple` to C,
 moving_average has no undefined `flags`.
 """
 from collections.abc import Iterable, Sequence
-from ctypes import c_double
+from ctypes import c_double, c_size_t
 
 from . import cdsp
 from .cdsp import byref_, dspdll
@@ -96,7 +96,21 @@ class RTIIRFilter(_RTFilterObject):
         return tuple(self._b[nb: nb + self._rtif.ifb.na])
 
     def state(self):
+        if self.is_sos():
+            return tuple(self._state[: 2 * self._rtif.ifb.fb.nb])
         return tuple(self._state[: max(self._rtif.ifb.na, self._rtif.ifb.fb.nb)])
+
+    def is_sos(self):
+        """True for a filter designed with FILTER_SOS: the bank holds packed sections, not b | a."""
+        return bool(self._rtif.rtf.flags & cdsp.FILTER_SOS) and self._rtif.ifb.na <= 1
+
+    def sections(self):
+        """[(b, a), ...] of a FILTER_SOS filter (three taps each)."""
+        arr = (cdsp.RTFilterSection_ * cdsp.DSP_MAX_SECTIONS)()
+        n = c_size_t()
+        if dspdll.RTIIRFilter_sos_sections(byref_(self._rtif), arr, cdsp.DSP_MAX_SECTIONS, byref_(n)):
+            raise ValueError("not a FILTER_SOS filter")
+        return [(tuple(arr[k].b), tuple(arr[k].a)) for k in range(n.value)]
 
 
 class RTFIRFilter(_RTFilterObject):
@@ -205,3 +219,61 @@ def filter_response_pzg(poles, zeros, kgain=1, freqs=None, n=200):
     dspdll.filter_response_pzg_noc(c_gain, c_phase, c_size_t(n), c_zeros_r, c_zeros_i, c_size_t(nz), c_poles_r,
                                    c_poles_i, c_size_t(npoles), c_double(kgain), c_freqs)
     return list(c_gain), list(c_phase), freqs
+
+
+# ---- additive design helpers (include/RTFilterDesign.h; no counterpart in python/dsp.py) ----------------------
+
+FILTER_SOS = cdsp.FILTER_SOS
+_FAMILIES = {"butterworth": cdsp.DSP_FAMILY_BUTTERWORTH, "chebyshev1": cdsp.DSP_FAMILY_CHEBYSHEV1,
+             "chebyshev2": cdsp.DSP_FAMILY_CHEBYSHEV2}
+_WINDOWS = {"rectangular": cdsp.DSP_WINDOW_RECTANGULAR, "hamming": cdsp.DSP_WINDOW_HAMMING,
+            "hann": cdsp.DSP_WINDOW_HANN, "blackman": cdsp.DSP_WINDOW_BLACKMAN}
+
+
+def design_sos(family, order, wlow, whigh, ripple=0.0):
+    """Second-order sections [(b, a), ...] of a classical design; the gain rides on section 0."""
+    arr = (cdsp.RTFilterSection_ * cdsp.DSP_MAX_SECTIONS)()
+    n = c_size_t()
+    status = dspdll.dsp_design_sos(_FAMILIES[family], order, ripple, wlow, whigh, arr, cdsp.DSP_MAX_SECTIONS,
+                                   byref_(n))
+    if status:
+        raise ValueError("dsp_design_sos(%s): status %d" % (family, status))
+    return [(tuple(arr[k].b), tuple(arr[k].a)) for k in range(n.value)]
+
+
+def design_batch(family, order, wlow, whigh, ripple=None, threads=0):
+    """Many designs of one family and order at once (host threads): arrays wlow[i], whigh[i] (and ripple[i]).
+    Returns (b, a, ncoef): float64 arrays of shape (n, 2*order+1) and the taps used per design; rows hold the
+    same bits butterworth / chebyshev1 / chebyshev2 produce one filter at a time."""
+    import numpy as np
+    wlow = np.ascontiguousarray(np.atleast_1d(wlow), dtype=np.float64)
+    whigh = np.ascontiguousarray(np.atleast_1d(whigh), dtype=np.float64)
+    n = len(wlow)
+    assert len(whigh) == n
+    ld = 2 * order + 1
+    b = np.zeros((n, ld))
+    a = np.zeros((n, ld))
+    nc = np.zeros(n, dtype=np.uintp)
+    rp = None
+    if ripple is not None:
+        rp = np.ascontiguousarray(np.broadcast_to(np.asarray(ripple, dtype=np.float64), (n,)))
+    dp = cdsp.POINTER(c_double)
+    status = dspdll.dsp_design_batch(_FAMILIES[family], n, order,
+                                     None if rp is None else rp.ctypes.data_as(dp),
+                                     wlow.ctypes.data_as(dp), whigh.ctypes.data_as(dp),
+                                     b.ctypes.data_as(dp), a.ctypes.data_as(dp), ld,
+                                     nc.ctypes.data_as(cdsp.POINTER(c_size_t)), threads)
+    if status:
+        raise ValueError("dsp_design_batch(%s): status %d" % (family, status))
+    return b, a, nc
+
+
+def windowed_sinc(taps, wlow, whigh, window="hamming", initialize=None):
+    """Windowed-sinc FIR (include/RTFilterDesign.h: fir_windowed_sinc); band conventions of butterworth."""
+    if initialize is not None:
+        initialize = cdsp.i_RTFilter__d(initialize)
+    rtff = RTFIRFilter([0.0] * taps, 0, initialize)
+    status = dspdll.fir_windowed_sinc(byref_(rtff.cobj()), taps, wlow, whigh, _WINDOWS[window], byref_(initialize))
+    if status:
+        raise ValueError("fir_windowed_sinc: status %d" % status)
+    return rtff

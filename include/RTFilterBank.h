@@ -42,6 +42,12 @@ typedef struct RTFilterBank RTFilterBank;
 #define RTFB_KIND_IIR          0   /* RTIIRFilter_update   + RTIIRFilter_stable_init  */
 #define RTFB_KIND_FIR          1   /* RTFIRFilter_update   + RTFIRFilter_stable_init  */
 #define RTFB_KIND_FIR_PARTIAL  2   /* RTFIRFilter_update   + RTFIRFilter_partial_init */
+#define RTFB_KIND_SOS          3   /* a cascade of second-order sections (FILTER_SOS; RTFilterDesign.h): nb = na =
+                                      3 x sections, b = the sections' numerators one after the other, a likewise
+                                      their denominators.  Every section is executed as an RTIIRFilter with
+                                      nb = na = 3 (RTIIRFilter_update + RTIIRFilter_stable_init) on the output of
+                                      the section before it; state: 3 slots per section, filtered_value of the
+                                      last section.  One pass over the block per section (16 B/sample each). */
 
 /* One distinct coefficient set; channels reference designs by index. */
 typedef struct RTFilterDesign {

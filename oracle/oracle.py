@@ -101,6 +101,39 @@ def fir(b, partial=False):
     return Filter(KIND_FIR, b, None, INIT_FIR_PARTIAL if partial else INIT_FIR_STABLE)
 
 
+class Cascade:
+    """Second-order sections in series: every section is an oracle IIR filter (nb = na = 3, the reference's
+    RTIIRFilter_update / RTIIRFilter_stable_init, each pinned to the reference) fed with the output of the
+    section before it.  The reference has no SOS execution (its FILTER_SOS flag is never read): this chain of
+    reference filters is the definition the product's RTFB_KIND_SOS path is held to."""
+
+    def __init__(self, sections):
+        self.sections = [iir(np.asarray(b, dtype=np.float64), np.asarray(a, dtype=np.float64)) for b, a in sections]
+
+    def reset(self):
+        for s in self.sections:
+            s.reset()
+
+    def updaten(self, x):
+        y = np.ascontiguousarray(x, dtype=np.float64)
+        for s in self.sections:
+            y = s.updaten(y)
+        return y
+
+    @property
+    def state(self):
+        """three slots per section, section after section (the layout of RTFilterBank_get_state)"""
+        return np.concatenate([s.state for s in self.sections])
+
+    @property
+    def filtered_value(self):
+        return self.sections[-1].filtered_value
+
+    @property
+    def initialized(self):
+        return self.sections[0].initialized
+
+
 class Bank:
     """Flat multichannel state: nch independent channels, each a reference filter.
 
