@@ -169,8 +169,7 @@ def main():
         wl = 0.25 + 0.1 * rng.random(CHANNELS)
         wu = wl + 0.25 + 0.05 * rng.random(CHANNELS)
         jb, ja, _ = dsp.design_batch("butterworth", 4, wl, wu)       # host threads, bits of dsp.butterworth
-        designs = [gbank.iir_design(jb[c], ja[c]) for c in range(CHANNELS)]
-        bank = gbank.FilterBank(designs, list(range(CHANNELS)), device=local, mode=mode)
+        bank = gbank.FilterBank.from_arrays(gbank.KIND_IIR, jb[:, :9], ja[:, :9], device=local, mode=mode)
     else:
         bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
 

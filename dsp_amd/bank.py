@@ -98,6 +98,39 @@ class FilterBank:
             self.set_mode(mode)
 
     @classmethod
+    def from_arrays(cls, kind, b, a=None, design_of_channel=None, device=0, mode=MODE_AUTO):
+        """Many designs of one kind and size from packed arrays (e.g. dsp.design_batch): b is (ndesign, nb), a is
+        (ndesign, na) for IIR.  The RTFilterDesign table is laid out with numpy instead of a Python loop over
+        ctypes structs (1.3 s per 2^18 designs); channel c runs design design_of_channel[c] (default: c)."""
+        self = cls.__new__(cls)
+        self._handle = C.c_void_p()
+        self.device = device
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        nd, nb = b.shape
+        rec = np.zeros(nd, dtype=np.dtype(dict(names=["kind", "nb", "na", "b", "a"],
+                                               formats=[np.int32, np.uintp, np.uintp, np.uintp, np.uintp],
+                                               offsets=[0, 8, 16, 24, 32], itemsize=C.sizeof(cdsp.RTFilterDesign_))))
+        rec["kind"] = kind
+        rec["nb"] = nb
+        rec["b"] = b.ctypes.data + np.arange(nd, dtype=np.uintp) * np.uintp(b.strides[0])
+        if a is not None:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            assert a.shape[0] == nd
+            rec["na"] = a.shape[1]
+            rec["a"] = a.ctypes.data + np.arange(nd, dtype=np.uintp) * np.uintp(a.strides[0])
+        self._keep = (b, a, rec)
+        idx = np.ascontiguousarray(np.arange(nd) if design_of_channel is None else design_of_channel, dtype=np.int32)
+        _check(dspdll.RTFilterBank_from_designs(C.byref(self._handle),
+                                                C.cast(rec.ctypes.data, C.POINTER(cdsp.RTFilterDesign_)), nd,
+                                                idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx), device),
+               "RTFilterBank_from_designs")
+        self.nch = len(idx)
+        self._filters = None
+        if mode != MODE_AUTO:
+            self.set_mode(mode)
+        return self
+
+    @classmethod
     def from_filters(cls, filters, device=0, mode=MODE_AUTO):
         """filters: dsp.RTIIRFilter / dsp.RTFIRFilter objects (their C structs are referenced)."""
         self = cls.__new__(cls)

@@ -164,6 +164,7 @@ _proto("RTFilterBank_from_filters", c_int, [POINTER(c_void_p), POINTER(c_void_p)
 _proto("RTFilterBank_from_designs", c_int,
        [POINTER(c_void_p), POINTER(RTFilterDesign_), c_size_t, POINTER(c_int32), c_size_t, c_int])
 _proto("dsp_scan_probe", c_int, [POINTER(RTFilterDesign_), POINTER(c_double)])
+_proto("dsp_scan_probe_kernel", c_int, [POINTER(RTFilterDesign_), c_int, POINTER(c_double)])
 _proto("dsp_bank_table_doubles", c_int, [POINTER(RTFilterDesign_), c_size_t, POINTER(c_size_t)])
 _proto("RTFilterBank_destroy", None, [c_void_p])
 _proto("RTFilterBank_channels", c_size_t, [c_void_p])

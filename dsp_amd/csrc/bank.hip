@@ -439,23 +439,46 @@ int scan2_levels(const double *pw, int N, int nlevels = kScan2Levels)
     return need;
 }
 
-/* Conditioning probe for the scan kernel (host, bank-creation time only; it
- * produces no output sample).  The scan kernel re-associates the recurrence
- * (zero-state pass + prefix combine with A^(T 2^k)), so its distance from the
- * reference's sequential arithmetic depends on the design's conditioning
+/* Conditioning probe for the scan kernels (host, bank-creation time only; it
+ * produces no output sample).  The scan kernels re-associate the recurrence
+ * (zero-state pass from the response table G, prefix combine with A^(T 2^k),
+ * carried state through row propagators or a virtual row), so their distance
+ * from the reference's sequential arithmetic depends on the design's conditioning
  * (SURVEY.md 0.5): ~1e-16 for the well-conditioned designs, 1e-8 and worse for
- * narrow-band / high-Q ones.  This runs the kernel's algorithm and the plain
- * recurrence side by side on two segments of pseudo-random input and returns
- * max|dy| / max|y|.  RTFB_MODE_AUTO sends a design to the scan kernel only if
- * the probe stays below kScanSafeError; otherwise its channels run on the
- * bit-exact sequential kernel. */
+ * narrow-band / high-Q ones.  This runs THE ALGORITHM OF THE KERNEL THAT WILL
+ * EXECUTE -- same row length T, same rows per segment, same tables (the very
+ * doubles the kernel reads), same order of the fused multiply-adds, same skipped
+ * levels -- next to the plain recurrence on two segments of pseudo-random input
+ * and returns max|dy| / max|y|.  (The order 9..16 kernel accumulates its two
+ * table-driven stages on the matrix cores, four terms per instruction; here they
+ * are one FMA chain in the same term order.)  RTFB_MODE_AUTO sends a design to
+ * its scan kernel only if the probe stays below kScanSafeError; otherwise its
+ * channels run on the bit-exact sequential kernel.
+ * The input is zero-mean noise of unit scale: the bound that AUTO inherits is
+ * relative to the larger of the output peak and the input scale seen through
+ * the filter's state (a stream dominated by DC or out-of-band content that the
+ * design rejects keeps the states at the input's scale while the output is
+ * small; re-association error stays relative to the former). */
 constexpr double kScanSafeError = 1e-13;     /* 10x margin under the 1e-12 parity bar */
 
 bool Design::scan_safe() const { return scan_error <= kScanSafeError; }
 
-double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
+struct ProbeKernel {
+    int T;                  /* samples per row                               */
+    int R;                  /* rows per segment                              */
+    bool propagators;       /* carried state by A^(T j) per row (pipelined kernel) instead of a virtual row -1 */
+};
+constexpr ProbeKernel kProbePipe = {kScan2T, kWave, true};         /* iir_pipe_kernel, orders <= 8, <= 1024 designs */
+constexpr ProbeKernel kProbeScan2 = {kScan2T, kScan2Rows, false};  /* iir_scan2_kernel, orders <= 8, more designs   */
+constexpr ProbeKernel kProbeScan16 = {kScanT, kWave, false};       /* iir_scan16_kernel, orders 9..16                */
+
+/* pw: nlev_table matrices A^(T 2^k), row-major; gtab: G[n][i], n < T, then Gc[i]; ttab: [e][j] (R = 64) or null */
+template <bool kHwFma>
+static inline __attribute__((always_inline)) double scan_probe_body(const Design &d, const ProbeKernel &pk,
+                                                                    const double *pw, int nlev, const double *gtab,
+                                                                    const double *ttab)
 {
-    const int N = d.nb - 1, T = kScanT, L = 2 * kWave * kScanT;
+    const int N = d.nb - 1, T = pk.T, R = pk.R, L = 2 * R * T, S = N + 1;
     std::vector<double> x(L), yref(L), y(L);
     uint64_t z = 0x243F6A8885A308D3ull;
     for (int k = 0; k < L; ++k) {                /* splitmix64 stream in [-1, 1) */
@@ -467,52 +490,75 @@ double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
         x[k] = (double)(int64_t)(h >> 11) * 0x1.0p-52 - 1.0;
     }
     const double *b = d.b.data(), *a = d.a.data();
-    auto step = [&](double xv, double *s) {      /* reference order, as iir_step_ref */
-        double t = xv * b[0];
-        t = t + s[0];
-        const double yv = t / a[0];
-        for (int i = 0; i < N; ++i) {
-            double u = 0.0 + b[i + 1] * xv;
-            u = u - a[i + 1] * yv;
-            s[i] = s[i + 1] + u;
+    const bool unit = a[0] == 1.0;
+    {
+        std::vector<double> s(S, 0.0);           /* reference order, as iir_step_ref */
+        for (int k = 0; k < L; ++k) {
+            double t = x[k] * b[0];
+            t = t + s[0];
+            const double yv = unit ? t : t / a[0];      /* x / 1.0 == x exactly */
+            for (int i = 0; i < N; ++i) {
+                double u = 0.0 + b[i + 1] * x[k];
+                u = u - a[i + 1] * yv;
+                s[i] = s[i + 1] + u;
+            }
+            yref[k] = yv;
         }
-        return yv;
-    };
-    auto step_fused = [&](double xv, double *s) {   /* as iir_step_fused */
-        double yv = std::fma(xv, b[0], s[0]);
-        if (a[0] != 1.0) yv = yv / a[0];
-        for (int i = 0; i < N; ++i) s[i] = std::fma(-a[i + 1], yv, std::fma(b[i + 1], xv, s[i + 1]));
-        return yv;
-    };
-    std::vector<double> sref(N + 1, 0.0);
-    for (int k = 0; k < L; ++k) yref[k] = step(x[k], sref.data());
-
-    std::vector<double> carry(N + 1, 0.0);
-    std::vector<std::vector<double>> v(kWave, std::vector<double>(N + 1));
-    for (int seg = 0; seg < L / (kWave * T); ++seg) {
-        const double *xs = &x[(size_t)seg * kWave * T];
-        double *ys = &y[(size_t)seg * kWave * T];
-        for (int j = 0; j < kWave; ++j) {
-            for (int i = 0; i < N; ++i) v[j][i] = j == 0 ? carry[i] : 0.0;
-            v[j][N] = carry[N];
-            for (int k = 0; k < T; ++k) step_fused(xs[j * T + k], v[j].data());
+    }
+    std::vector<double> carry(S, 0.0), v((size_t)R * N), vold((size_t)R * N), s(S);
+    for (int seg = 0; seg < 2; ++seg) {
+        const double *xs = &x[(size_t)seg * R * T];
+        double *ys = &y[(size_t)seg * R * T];
+        /* zero-state pass: v_j = sum_n G[n] x[n], n ascending (+ Gc * s[N], the never-written slot) */
+        for (int j = 0; j < R; ++j) {
+            double *vj = &v[(size_t)j * N];
+            for (int i = 0; i < N; ++i) vj[i] = 0.0;
+            for (int n = 0; n < T; ++n) {
+                const double xv = xs[j * T + n];
+                for (int i = 0; i < N; ++i) vj[i] = __builtin_fma(gtab[n * N + i], xv, vj[i]);
+            }
+            if (carry[N] != 0.0)
+                for (int i = 0; i < N; ++i) vj[i] = __builtin_fma(gtab[T * N + i], carry[N], vj[i]);
         }
-        for (int lvl = 0; lvl < kScanLevels; ++lvl) {
+        /* Kogge-Stone over the rows; levels whose matrix has decayed are skipped as in the kernel */
+        for (int lvl = 0; lvl < nlev; ++lvl) {
             const int dist = 1 << lvl;
-            const double *M = &pows_of_design[(size_t)lvl * N * N];
-            for (int j = kWave - 1; j >= dist; --j)
+            if (dist > R) break;
+            const double *M = pw + (size_t)lvl * N * N;
+            vold = v;
+            for (int j = 0; j < R; ++j) {
+                const double *u = j >= dist ? &vold[(size_t)(j - dist) * N]
+                                            : (!pk.propagators && j == dist - 1 ? carry.data() : nullptr);
+                if (!u) continue;
+                double *vj = &v[(size_t)j * N];
                 for (int i = 0; i < N; ++i) {
-                    double acc = v[j][i];
-                    for (int q = 0; q < N; ++q) acc = std::fma(M[i * N + q], v[j - dist][q], acc);
-                    v[j][i] = acc;              /* j descending: v[j-dist] is still the old value */
+                    double acc = vj[i];
+                    for (int q = 0; q < N; ++q) acc = __builtin_fma(M[i * N + q], u[q], acc);
+                    vj[i] = acc;
                 }
+            }
         }
-        std::vector<double> s(N + 1), next(N + 1);
-        for (int j = 0; j < kWave; ++j) {
-            for (int i = 0; i < N; ++i) s[i] = j == 0 ? carry[i] : v[j - 1][i];
+        /* true pass: row j from its start state */
+        std::vector<double> next(S);
+        for (int j = 0; j < R; ++j) {
+            if (pk.propagators) {                /* s_j = P_j + A^(T j) carry, P_0 = 0 */
+                for (int i = 0; i < N; ++i) {
+                    double acc = j ? v[(size_t)(j - 1) * N + i] : 0.0;
+                    for (int q = 0; q < N; ++q) acc = __builtin_fma(ttab[(size_t)(i * N + q) * kWave + j], carry[q], acc);
+                    s[i] = acc;
+                }
+            } else {
+                for (int i = 0; i < N; ++i) s[i] = j ? v[(size_t)(j - 1) * N + i] : carry[i];
+            }
             s[N] = carry[N];
-            for (int k = 0; k < T; ++k) ys[j * T + k] = step_fused(xs[j * T + k], s.data());
-            if (j == kWave - 1) next = s;
+            for (int k = 0; k < T; ++k) {        /* as iir_step_fused */
+                const double xv = xs[j * T + k];
+                double yv = __builtin_fma(xv, b[0], s[0]);
+                if (!unit) yv = yv / a[0];
+                for (int i = 0; i < N; ++i) s[i] = __builtin_fma(-a[i + 1], yv, __builtin_fma(b[i + 1], xv, s[i + 1]));
+                ys[j * T + k] = yv;
+            }
+            if (j == R - 1) next = s;
         }
         carry = next;
     }
@@ -524,6 +570,73 @@ double scan_probe(const Design &d, const std::vector<double> &pows_of_design)
     }
     if (!(peak > 0.0)) return err == 0.0 ? 0.0 : HUGE_VAL;
     return err / peak;
+}
+
+/* hipcc builds host code for baseline x86-64, where __builtin_fma is a libm call (~5 ns): the probe of one
+ * design then takes over a millisecond and a bank of 65 536 distinct designs tens of seconds.  Hosts with FMA
+ * units (every host of an MI355X) take the instantiation compiled for them; same IEEE results either way. */
+__attribute__((target("fma"))) double scan_probe_hw(const Design &d, const ProbeKernel &pk, const double *pw, int nlev,
+                                                    const double *gtab, const double *ttab)
+{
+    return scan_probe_body<true>(d, pk, pw, nlev, gtab, ttab);
+}
+
+double scan_probe_sw(const Design &d, const ProbeKernel &pk, const double *pw, int nlev, const double *gtab,
+                     const double *ttab)
+{
+    return scan_probe_body<false>(d, pk, pw, nlev, gtab, ttab);
+}
+
+double scan_probe(const Design &d, const ProbeKernel &pk, const double *pw, int nlev, const double *gtab,
+                  const double *ttab)
+{
+    static const bool hw = __builtin_cpu_supports("fma");
+    return hw ? scan_probe_hw(d, pk, pw, nlev, gtab, ttab) : scan_probe_sw(d, pk, pw, nlev, gtab, ttab);
+}
+
+/* The kernel RTFilterBank_updaten sends a scan-safe design to (see there) */
+const ProbeKernel &probe_kernel_of(int order, size_t ndesigns)
+{
+    if (order > kScan2MaxOrder) return kProbeScan16;
+    return ndesigns <= kMaxPipeDesigns ? kProbePipe : kProbeScan2;
+}
+
+/* Build every table of one design into `mine` (layout of design_table_doubles) and probe the kernel `pk`. */
+struct DesignTables {
+    size_t pow = 0, gtab1 = 0, pow2 = 0, gtab = 0, ttab = (size_t)-1;
+    int levels1 = 0, levels2 = 0;
+    double scan_error = HUGE_VAL;
+};
+
+DesignTables build_design_tables(const Design &d, bool with_ttab, const ProbeKernel &pk, std::vector<double> &mine)
+{
+    DesignTables t;
+    const int N = d.nb - 1;
+    mine.clear();
+    /* A^(64 2^k), k < 6, are levels 1..6 of A^(32 2^k), k < 7 (same squarings, same bits): one chain serves both */
+    static_assert(kScanT == 2 * kScan2T && kScan2Levels == kScanLevels + 1, "the two power tables share a chain");
+    std::vector<double> chain;
+    scan_powers(d, kScan2T, kScan2Levels, chain);
+    mine.insert(mine.end(), chain.begin() + (size_t)N * N, chain.end());
+    t.levels1 = scan2_levels(mine.data(), N, kScanLevels);
+    t.gtab1 = mine.size();
+    scan2_gtable(d, kScanT, mine);
+    t.pow2 = mine.size();
+    mine.insert(mine.end(), chain.begin(), chain.end());
+    t.levels2 = scan2_levels(&mine[t.pow2], N);
+    t.gtab = mine.size();
+    scan2_gtable(d, kScan2T, mine);
+    if (N <= kScan2MaxOrder && with_ttab) {
+        t.ttab = mine.size();
+        pipe_ttable(d, kScan2T, mine);
+    }
+    if (pk.T == kScanT)
+        t.scan_error = scan_probe(d, pk, &mine[t.pow], t.levels1, &mine[t.gtab1], nullptr);
+    else if (pk.propagators && t.ttab != (size_t)-1)
+        t.scan_error = scan_probe(d, pk, &mine[t.pow2], std::min(t.levels2, kScanLevels), &mine[t.gtab], &mine[t.ttab]);
+    else
+        t.scan_error = scan_probe(d, kProbeScan2, &mine[t.pow2], t.levels2, &mine[t.gtab], nullptr);
+    return t;
 }
 
 void free_bank_device(RTFilterBank *b)
@@ -663,23 +776,15 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
                 if (i >= nd) break;
                 Design &d = bk->designs[i];
                 if (!d.has_tables) continue;
-                mine.clear();
                 const size_t base = (size_t)d.pow_off;
-                scan_powers(d, kScanT, kScanLevels, mine);
-                d.scan_error = scan_probe(d, mine);
-                d.levels1 = scan2_levels(mine.data(), d.nb - 1, kScanLevels);
-                d.gtab1_off = (int)(base + mine.size());
-                scan2_gtable(d, kScanT, mine);
-                d.pow2_off = (int)(base + mine.size());
-                const size_t p2 = mine.size();
-                scan_powers(d, kScan2T, kScan2Levels, mine);
-                d.levels2 = scan2_levels(&mine[p2], d.nb - 1);
-                d.gtab_off = (int)(base + mine.size());
-                scan2_gtable(d, kScan2T, mine);
-                if (d.nb - 1 <= kScan2MaxOrder && with_ttab) {
-                    d.ttab_off = (int)(base + mine.size());
-                    pipe_ttable(d, kScan2T, mine);
-                }
+                const DesignTables t = build_design_tables(d, with_ttab, probe_kernel_of(d.nb - 1, nd), mine);
+                d.scan_error = t.scan_error;
+                d.levels1 = t.levels1;
+                d.levels2 = t.levels2;
+                d.gtab1_off = (int)(base + t.gtab1);
+                d.pow2_off = (int)(base + t.pow2);
+                d.gtab_off = (int)(base + t.gtab);
+                if (t.ttab != (size_t)-1) d.ttab_off = (int)(base + t.ttab);
                 std::copy(mine.begin(), mine.end(), pows.begin() + (long)base);
             }
         };
@@ -982,9 +1087,31 @@ int dsp_scan_probe(const RTFilterDesign *design, double *rel_error)
     d.b.assign(design->b, design->b + d.nb);
     if (d.na) d.a.assign(design->a, design->a + d.na);
     if (!d.fast_iir()) return fail(RTFB_EUNSUPPORTED, "the scan kernel takes IIR designs with na == nb <= 17");
-    std::vector<double> pows;
-    scan_powers(d, kScanT, kScanLevels, pows);
-    *rel_error = scan_probe(d, pows);
+    std::vector<double> mine;
+    *rel_error = build_design_tables(d, true, probe_kernel_of(d.nb - 1, 1), mine).scan_error;
+    return RTFB_OK;
+}
+
+int dsp_scan_probe_kernel(const RTFilterDesign *design, int kernel, double *rel_error)
+{
+    if (!design || !rel_error) return fail(RTFB_EINVAL, "dsp_scan_probe_kernel: NULL argument");
+    int rc = validate_design(*design);
+    if (rc) return rc;
+    Design d;
+    d.kind = design->kind;
+    d.nb = (int)design->nb;
+    d.na = d.kind == RTFB_KIND_IIR ? (int)design->na : 0;
+    d.b.assign(design->b, design->b + d.nb);
+    if (d.na) d.a.assign(design->a, design->a + d.na);
+    if (!d.fast_iir()) return fail(RTFB_EUNSUPPORTED, "the scan kernels take IIR designs with na == nb <= 17");
+    const int N = d.nb - 1;
+    const ProbeKernel *pk = nullptr;
+    if (kernel == RTFB_SCAN_KERNEL_PIPE && N <= kScan2MaxOrder) pk = &kProbePipe;
+    else if (kernel == RTFB_SCAN_KERNEL_SCAN2 && N <= kScan2MaxOrder) pk = &kProbeScan2;
+    else if (kernel == RTFB_SCAN_KERNEL_SCAN16 && N > kScan2MaxOrder) pk = &kProbeScan16;
+    if (!pk) return fail(RTFB_EINVAL, "dsp_scan_probe_kernel: that kernel does not serve this order");
+    std::vector<double> mine;
+    *rel_error = build_design_tables(d, true, *pk, mine).scan_error;
     return RTFB_OK;
 }
 

@@ -87,11 +87,22 @@ EXPORT int RTFilterBank_from_designs(RTFilterBank **bank, const RTFilterDesign *
                                      size_t ndesign, const int32_t *design_of_channel,
                                      size_t nch, int device);
 
-/* Conditioning probe used by RTFB_MODE_AUTO (host arithmetic, no device needed, produces no
- * filter output): runs the scan kernel's re-associated algorithm against the plain recurrence on
- * pseudo-random input and reports max|dy|/max|y|.  Designs above 1e-13 are kept on the sequential
- * kernel in AUTO mode.  RTFB_EUNSUPPORTED unless IIR with na == nb <= 17. */
+/* Conditioning probe used by RTFB_MODE_AUTO (host arithmetic, no device needed, produces no filter output):
+ * runs the re-associated algorithm of the scan kernel the design would execute on -- same row length, rows per
+ * segment, tables, order of the fused multiply-adds and skipped combine levels -- against the plain recurrence on
+ * pseudo-random input of unit scale and reports max|dy|/max|y|.  Designs above 1e-13 are kept on the sequential
+ * kernel in AUTO mode.  dsp_scan_probe picks the kernel of a bank with few designs (pipelined kernel for orders
+ * <= 8, matrix-core scan for 9..16); dsp_scan_probe_kernel names it.  RTFB_EUNSUPPORTED unless IIR with
+ * na == nb <= 17.
+ * What AUTO promises: 1e-12 relative to the larger of the output peak and the scale of the filter's state.  For
+ * zero-mean broadband input those coincide; a stream dominated by DC or out-of-band content that the design
+ * rejects keeps the state at the input's scale while the output is small, and the re-association error stays
+ * relative to the former.  RTFB_MODE_SEQUENTIAL is the bit-exact mode. */
+#define RTFB_SCAN_KERNEL_PIPE    0   /* orders <= 8, banks of <= 1024 distinct designs */
+#define RTFB_SCAN_KERNEL_SCAN2   1   /* orders <= 8, banks of more designs             */
+#define RTFB_SCAN_KERNEL_SCAN16  2   /* orders 9..16                                   */
 EXPORT int dsp_scan_probe(const RTFilterDesign *design, double *rel_error);
+EXPORT int dsp_scan_probe_kernel(const RTFilterDesign *design, int kernel, double *rel_error);
 
 /* Host arithmetic only: doubles of per-design scan tables a bank of these designs carries at most (fast IIR
  * designs: matrix powers, zero-state response tables, row propagators).  The kernels address those tables with
