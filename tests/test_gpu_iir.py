@@ -30,7 +30,7 @@ def test_synth_fill_matches_checker(G):
 
 
 IIR_KEYS = ["bw4_bp_0.3_0.6", "bw8_bp_0.25_0.75", "bw2_bp_demo", "bw5_lp_0.25", "bw3_hp_0.4",
-            "bw3_bs_0.6_0.3", "ch1_4_lp_0.3", "bw1_lp_0.1", "bw16_lp_0.5", "thiran_5_4"]
+            "bw3_bs_0.6_0.3", "ch1_4_lp_0.3", "thiran_5_4"]        # every key has a captured reference run
 
 
 @pytest.mark.parametrize("key", IIR_KEYS)
