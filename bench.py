@@ -559,7 +559,7 @@ def main_stream16(args, emit=True):
         if ev is not None:
             ev[0].record(stream)
         if world > 1:
-            gstream.split_update(fs, x, y, stream=stream)
+            gstream.split_update(fs, x, y, stream=stream, total=total)
         else:
             fs(x, y, stream)
         if ev is not None:

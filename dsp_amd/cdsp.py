@@ -206,6 +206,9 @@ _proto("RTFilterStream_pack_len", c_size_t, [c_void_p])
 _proto("RTFilterStream_export_state", c_int, [c_void_p, c_void_p, c_void_p])
 _proto("RTFilterStream_import_state", c_int, [c_void_p, c_void_p, c_void_p])
 _proto("RTFilterStream_tail_state", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p])
+_proto("RTFilterStream_exact_split", c_int, [c_void_p])
+_proto("RTFilterStream_zero_state", c_int, [c_void_p, c_void_p])
+_proto("RTFilterStream_compose_state", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterStream_get_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
 _proto("RTFilterStream_set_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
 

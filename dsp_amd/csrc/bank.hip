@@ -1583,6 +1583,7 @@ constexpr size_t kStreamMinSplit = 8;         /* below this the sequential path 
 constexpr size_t kStreamGrain = 2048;         /* sub-chunk lengths are multiples of the scan segment */
 constexpr size_t kStreamMaxDecay = (size_t)1 << 20;
 constexpr long double kStreamNegligible = 0x1.0p-80L;
+constexpr size_t kStreamExactChunk = 16384;   /* exact composition: sub-chunks of at least this many samples */
 
 struct SplitBanks {
     RTFilterBank *main = nullptr;             /* C channels: the sub-chunks */
@@ -1602,6 +1603,9 @@ struct RTFilterStream {
     std::map<size_t, SplitBanks> split;       /* by C */
     double *d_scratch = nullptr;              /* outputs of the run-ups (discarded) */
     size_t scratch_doubles = 0;
+    bool exact_ok = false;                    /* chunk maps may be composed exactly (scan-safe fast IIR) */
+    bool maybe_fresh = true;                  /* the next sample may go to the initialiser (host-side view) */
+    std::map<size_t, double *> d_power;       /* chunk length L -> A^L (N x N, row-major) on the device */
     /* RTFilterStream_updaten_host: two device chunk pairs and three streams, created on first use */
     double *d_hin[2] = {nullptr, nullptr}, *d_hout[2] = {nullptr, nullptr};
     hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
@@ -1724,6 +1728,79 @@ int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t
     return RTFB_OK;
 }
 
+/* A^L for the homogeneous recurrence (long double, binary powering), cached on the device per L. */
+int chunk_power(RTFilterStream *st, size_t L, const double **dev)
+{
+    auto it = st->d_power.find(L);
+    if (it != st->d_power.end()) {
+        *dev = it->second;
+        return RTFB_OK;
+    }
+    const int N = (int)st->a.size() - 1;
+    typedef std::vector<long double> Mat;
+    auto mul = [N](const Mat &p, const Mat &q) {
+        Mat r((size_t)N * N, 0.0L);
+        for (int i = 0; i < N; ++i)
+            for (int k = 0; k < N; ++k) {
+                const long double pik = p[(size_t)i * N + k];
+                for (int j = 0; j < N; ++j) r[(size_t)i * N + j] += pik * q[(size_t)k * N + j];
+            }
+        return r;
+    };
+    Mat P((size_t)N * N, 0.0L), R((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i) {
+        P[(size_t)i * N] = -(long double)st->a[i + 1] / (long double)st->a[0];
+        if (i + 1 < N) P[(size_t)i * N + i + 1] += 1.0L;
+        R[(size_t)i * N + i] = 1.0L;
+    }
+    for (size_t e = L; e; e >>= 1) {
+        if (e & 1) R = mul(R, P);
+        if (e > 1) P = mul(P, P);
+    }
+    std::vector<double> host((size_t)N * N);
+    for (size_t e = 0; e < host.size(); ++e) host[e] = (double)R[e];
+    void *p = nullptr;
+    int rc = pool_alloc(&p, host.size() * sizeof(double), st->device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    st->d_power[L] = static_cast<double *>(p);
+    *dev = static_cast<double *>(p);
+    return RTFB_OK;
+}
+
+/* One time-split piece WITHOUT a decay assumption: the chunk maps are composed exactly.
+ * Pass A filters sub-chunks 0 .. C-2 from the zero state (their outputs land in `out` and are overwritten by
+ * pass B) and leaves their zero-state end states v_c; s_c = A^Lc s_(c-1) + v_(c-1) gives every sub-chunk its
+ * start state; pass B is the ordinary launch.  Twice the traffic of the decay shortcut, C-fold parallel where
+ * the alternative is one workgroup.  in and out must not overlap; the stream must be running (not fresh). */
+int stream_split_piece_exact(RTFilterStream *st, double *out, const double *in, size_t C, size_t Lc, hipStream_t s)
+{
+    SplitBanks *sb = nullptr;
+    int rc = split_banks(st, C, &sb);
+    if (rc) return rc;
+    const double *d_M = nullptr;
+    if ((rc = chunk_power(st, Lc, &d_M))) return rc;
+    Group &gm = sb->main->groups[0], &gw = sb->warm->groups[0], &g1 = st->one->groups[0];
+    const size_t ld = (size_t)gm.state_ld;
+    const int N = (int)st->a.size() - 1;
+
+    HIP_TRY(hipMemsetAsync(gw.d_state, 0, (C - 1) * ld * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(gw.d_init, 0, (C - 1) * sizeof(int32_t), s));
+    if ((rc = RTFilterBank_updaten(sb->warm, out, Lc, in, Lc, Lc, s))) return rc;
+
+    HIP_TRY(hipMemcpyAsync(gm.d_state, g1.d_state, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(gm.d_fval, g1.d_fval, sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(gm.d_init, 0, C * sizeof(int32_t), s));
+    HIP_TRY(launch_compose_states(gm.d_state, ld, g1.d_state, gw.d_state, ld, d_M, N, (int)C, 1, s));
+
+    if ((rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s))) return rc;
+
+    HIP_TRY(hipMemcpyAsync(g1.d_state, gm.d_state + (C - 1) * ld, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(g1.d_fval, gm.d_fval + (C - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(g1.d_init, 0, sizeof(int32_t), s));
+    return RTFB_OK;
+}
+
 int stream_create(RTFilterStream **stream, RTFilterStream *st)
 {
     int rc = RTFB_OK;
@@ -1731,6 +1808,7 @@ int stream_create(RTFilterStream **stream, RTFilterStream *st)
         st->one->designs[0].scan_safe() && iir_scan_supported(st->one->groups[0].order)) {
         st->decay = decay_length(st->a);
         if (st->decay) rc = one_channel_bank(&st->tail, st);
+        st->exact_ok = true;
     }
     if (rc) {
         RTFilterStream_destroy(st);
@@ -1791,6 +1869,7 @@ void RTFilterStream_destroy(RTFilterStream *st)
     RTFilterBank_destroy(st->tail);
     RTFilterBank_destroy(st->one);             /* synchronises the device */
     pool_free(st->d_scratch);
+    for (auto &kv : st->d_power) pool_free(kv.second);
     {
         DeviceScope ds(st->device);
         for (int k = 0; k < 2; ++k) {
@@ -1819,11 +1898,31 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     st->last_split = 1;
     bool first = true;
+    const bool overlap = in < out + n && out < in + n;
     while (n) {
         /* sub-chunk: at least 4 decay lengths (the run-up costs M/Lc extra) and 8192 samples */
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
         size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
+        bool exact = false;
+        if (C < kStreamMinSplit && st->exact_ok && !overlap) {
+            /* no (usable) decay: compose the chunk maps exactly instead of falling to one workgroup.  A stream
+             * that may still be fresh first sends one segment through the sequential path, which runs the
+             * initialiser on sample 0 (the composition needs affine maps). */
+            if (st->maybe_fresh && n > kStreamGrain) {
+                int rc = RTFilterBank_updaten(st->one, out, kStreamGrain, in, kStreamGrain, kStreamGrain, s);
+                if (rc) return rc;
+                st->maybe_fresh = false;
+                out += kStreamGrain;
+                in += kStreamGrain;
+                n -= kStreamGrain;
+            }
+            const size_t Ce = std::min(kStreamMaxSplit, n / kStreamExactChunk);
+            if (Ce >= kStreamMinSplit && !st->maybe_fresh) {
+                C = Ce;
+                exact = true;
+            }
+        }
         if (C < kStreamMinSplit) {                    /* sequential: the one-channel bank itself */
             int rc = RTFilterBank_updaten(st->one, out, n, in, n, n, s);
             if (rc) return rc;
@@ -1832,12 +1931,13 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         const size_t Lc = n / C / kStreamGrain * kStreamGrain;
         if (first) st->last_split = C;
         first = false;
-        int rc = stream_split_piece(st, out, in, C, Lc, s);
+        int rc = exact ? stream_split_piece_exact(st, out, in, C, Lc, s) : stream_split_piece(st, out, in, C, Lc, s);
         if (rc) return rc;
         out += C * Lc;
         in += C * Lc;
         n -= C * Lc;
     }
+    st->maybe_fresh = false;
     return RTFB_OK;
 }
 
@@ -1891,6 +1991,7 @@ int RTFilterStream_updaten_host(RTFilterStream *st, double *out, const double *i
 int RTFilterStream_reset(RTFilterStream *st, void *hip_stream)
 {
     if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    st->maybe_fresh = true;
     return RTFilterBank_reset(st->one, hip_stream);
 }
 
@@ -1924,6 +2025,46 @@ int RTFilterStream_import_state(RTFilterStream *st, const double *pack_dev, void
     const Group &g = st->one->groups[0];
     HIP_TRY(launch_state_unpack(pack_dev, g.d_state, g.d_fval, g.d_init, g.state_ld,
                                 static_cast<hipStream_t>(hip_stream)));
+    st->maybe_fresh = true;                  /* the imported `initialized` is not known on the host */
+    return RTFB_OK;
+}
+
+int RTFilterStream_exact_split(const RTFilterStream *st) { return st && st->exact_ok ? 1 : 0; }
+
+int RTFilterStream_zero_state(RTFilterStream *st, void *hip_stream)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const Group &g = st->one->groups[0];
+    HIP_TRY(hipMemsetAsync(g.d_state, 0, (size_t)g.state_ld * sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.d_fval, 0, sizeof(double), s));
+    HIP_TRY(hipMemsetAsync(g.d_init, 0, sizeof(int32_t), s));
+    st->maybe_fresh = false;
+    return RTFB_OK;
+}
+
+int RTFilterStream_compose_state(RTFilterStream *st, const double *packs_dev, size_t stride, size_t count,
+                                 size_t chunk_len, void *hip_stream)
+{
+    if (!st || !packs_dev || !count) return fail(RTFB_EINVAL, "RTFilterStream_compose_state: NULL or empty argument");
+    if (!st->exact_ok) return fail(RTFB_EUNSUPPORTED, "RTFilterStream_compose_state: chunk maps of this design are not composed");
+    const Group &g = st->one->groups[0];
+    if (stride < (size_t)g.state_ld + 2 || count > (size_t)1 << 20)
+        return fail(RTFB_EINVAL, "RTFilterStream_compose_state: stride smaller than a hand-off vector");
+    DeviceScope ds(st->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const double *d_M = nullptr;
+    int rc = chunk_power(st, chunk_len, &d_M);
+    if (rc) return rc;
+    const int N = (int)st->a.size() - 1;
+    HIP_TRY(launch_compose_states(g.d_state, 0, packs_dev, packs_dev + stride, stride, d_M, N, (int)count, 0, s));
+    HIP_TRY(hipMemcpyAsync(g.d_fval, packs_dev + (count - 1) * stride + g.state_ld, sizeof(double),
+                           hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(g.d_init, 0, sizeof(int32_t), s));
+    st->maybe_fresh = false;
     return RTFB_OK;
 }
 
@@ -1959,6 +2100,7 @@ int RTFilterStream_set_state(RTFilterStream *st, const double *state, const doub
                              void *hip_stream)
 {
     if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    st->maybe_fresh = true;
     return RTFilterBank_set_state(st->one, state, fval, init, hip_stream);
 }
 

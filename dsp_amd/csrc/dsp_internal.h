@@ -96,6 +96,8 @@ hipError_t launch_state_pack(double *pack, const double *state, const double *fv
                              int ld, hipStream_t s);
 hipError_t launch_state_unpack(const double *pack, double *state, double *fval, int32_t *init, int ld,
                                hipStream_t s);
+hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0, const double *v, size_t v_ld,
+                                 const double *M, int N, int count, int write_all, hipStream_t s);
 bool iir_scan_supported(int order);
 
 }  // namespace dsp

@@ -797,6 +797,42 @@ __global__ void state_unpack_kernel(const double *pack, double *state, double *f
     }
 }
 
+/* Composition of the affine chunk maps of one filter: with s_end = M s_start + v per chunk
+ * (M = A^L for chunks of L samples, v the chunk's zero-state end state), the start state of chunk c is
+ *     s_c = M s_(c-1) + v_(c-1),      s_0 given.
+ * One wavefront; lane i owns state slot i (N <= 16), M and the running state live in LDS.  `src0` is s_0
+ * (N+1 slots: the never-written slot N rides along unchanged), v rows are v_ld apart.  write_all != 0: row c of
+ * dst (dst_ld apart) receives s_c for c = 1 .. count-1 (row 0 is left alone); else only the final s_(count-1) is
+ * written, to dst row 0.  count >= 1 (count == 1: the result is s_0 itself). */
+__global__ void __launch_bounds__(kWave)
+compose_states_kernel(double *dst, size_t dst_ld, const double *src0, const double *v, size_t v_ld,
+                      const double *M, int N, int count, int write_all)
+{
+    __shared__ double Ms[16 * 16];
+    __shared__ double sbuf[2][17];
+    const int i = threadIdx.x;
+    for (int e = i; e < N * N; e += kWave) Ms[e] = M[e];
+    if (i <= N) sbuf[0][i] = src0[i];
+    __builtin_amdgcn_wave_barrier();
+    const double tail = sbuf[0][N];
+    int cur = 0;
+    for (int c = 1; c < count; ++c) {
+        double acc = 0.0;
+        if (i < N) {
+            acc = v[(size_t)(c - 1) * v_ld + i];
+            for (int q = 0; q < N; ++q) acc = __builtin_fma(Ms[i * N + q], sbuf[cur][q], acc);
+            sbuf[cur ^ 1][i] = acc;
+            if (write_all) dst[(size_t)c * dst_ld + i] = acc;
+        } else if (i == N) {
+            sbuf[cur ^ 1][N] = tail;
+            if (write_all) dst[(size_t)c * dst_ld + N] = tail;
+        }
+        cur ^= 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!write_all && i <= N) dst[i] = sbuf[cur][i];
+}
+
 /* Synthetic input generator; two samples per thread. */
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 {
@@ -957,6 +993,15 @@ hipError_t launch_state_unpack(const double *pack, double *state, double *fval, 
 {
     hipLaunchKernelGGL(state_unpack_kernel, dim3(1), dim3(((ld + 63) / 64) * 64), 0, s, pack, state, fval, init,
                        ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0, const double *v, size_t v_ld,
+                                 const double *M, int N, int count, int write_all, hipStream_t s)
+{
+    if (N < 1 || N > 16 || count < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(compose_states_kernel, dim3(1), dim3(kWave), 0, s, dst, dst_ld, src0, v, v_ld, M, N, count,
+                       write_all);
     return hipGetLastError();
 }
 

@@ -115,6 +115,21 @@ class FilterStream:
         _check(rc, "RTFilterStream_tail_state")
         return True
 
+    # ---- exact composition of chunk maps (include/RTFilterStream.h) ----
+    @property
+    def exact_split(self):
+        return bool(dspdll.RTFilterStream_exact_split(self._h))
+
+    def zero_state(self, stream=None):
+        _check(dspdll.RTFilterStream_zero_state(self._h, _stream_ptr(stream, self.device)), "RTFilterStream_zero_state")
+
+    def compose_state(self, packs, count, chunk_len, stream=None):
+        """packs: (>= count, stride) device tensor of hand-off vectors p_0 .. p_(count-1); the stream's state
+        becomes A^L(...(A^L p_0 + p_1)...) + p_(count-1) for chunks of L = chunk_len samples."""
+        _check(dspdll.RTFilterStream_compose_state(self._h, C.c_void_p(packs.data_ptr()), packs.stride(0), count,
+                                                   chunk_len, _stream_ptr(stream, self.device)),
+               "RTFilterStream_compose_state")
+
     def get_state(self, stream=None):
         ld = self.pack_len - 2
         st = np.zeros(ld, dtype=np.float64)
@@ -139,19 +154,55 @@ def time_range(n, world_size, rank, grain=2048):
     return lo, (n if rank == world_size - 1 else lo + per)
 
 
-def split_update(engine, x_local, out_local=None, group=None, stream=None):
-    """`RTFilter_updaten` over a stream whose consecutive chunks live on consecutive ranks.
+def _plan(engine, numel, world, rank, group, total):
+    """Chunk lengths of all ranks and the hand-off mode, decided once per (engine, chunk length, world) and kept:
+    'tail' (one all_gather, nothing else), 'exact' (chunk maps composed), 'chain' (send/recv of true end states)."""
+    import torch
+    import torch.distributed as dist
+    key = (numel, world, rank, total)
+    plans = engine.__dict__.setdefault("_split_plans", {})
+    if key in plans:
+        return plans[key]
+    if total is not None:
+        lens = [hi - lo for lo, hi in (time_range(total, world, r) for r in range(world))]
+        assert lens[rank] == numel, "x_local does not hold time_range(total, world, rank)"
+    else:                                                   # one small host collective, first call only
+        mine = torch.tensor([numel], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            mine = mine.cuda()
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine, group=group)
+        lens = [int(t.item()) for t in got]
+    decay = int(getattr(engine, "decay_length", 0) or 0)
+    feeders = lens[:-1]                                     # the last rank hands nothing on
+    if decay and all(n >= decay for n in feeders):
+        mode = "tail"
+    elif getattr(engine, "exact_split", False) and all(n == lens[1] for n in lens[1:-1]) and all(n > 0 for n in feeders):
+        mode = "exact"
+    else:
+        mode = "chain"
+    plans[key] = (lens, mode)
+    return plans[key]
 
-    `engine`: a FilterStream (or anything with its hand-off methods: new_pack, tail_state,
-    export_state, import_state, __call__).  Rank 0's engine holds the state carried into the stream;
-    on return EVERY rank's engine holds the state at the end of the whole stream (so that the
-    next call may repartition), and each rank's chunk of the output is returned.
 
-    Hand-off: ranks whose chunk allows it compute the zero-state tail vector of their own chunk and
-    all ranks all_gather these vectors (one small collective: pack_len doubles per rank); rank r
-    then imports rank r-1's vector and all ranks filter concurrently.  If any rank reports that the
-    tail shortcut does not apply (filter does not decay, chunk too short) the ranks chain instead:
-    rank r waits for rank r-1's true end state (send/recv), which serialises them but is exact.
+def split_update(engine, x_local, out_local=None, group=None, stream=None, total=None):
+    """`RTFilter_updaten` over a stream whose consecutive chunks live on consecutive ranks (time_range).
+
+    `engine`: a FilterStream (or anything with its hand-off methods).  The state carried INTO the stream is rank
+    0's engine state on the first call; afterwards the stream's end state lives on the LAST rank and rides back to
+    rank 0 inside the next call's all_gather, so consecutive calls continue one stream (`sync_end_state` puts it on
+    every rank when a caller needs that, e.g. before repartitioning).  `total`: the stream length of this call, if
+    the caller knows it -- the hand-off mode is then decided without any communication; otherwise the chunk lengths
+    are exchanged once per (chunk length, world size) and remembered.
+
+    Modes (fixed per engine and partition, no per-call negotiation, no host synchronisation on RCCL):
+      tail   the design forgets within its decay length M <= every feeding chunk: each rank computes the hand-off
+             vector of its own chunk from its last M samples; ONE all_gather (2 x pack_len doubles per rank: that
+             vector and the rank's state at entry) moves everything; all ranks filter concurrently.
+      exact  no usable decay: chunk maps are composed (RTFilterStream.h): ranks >= 1 run their chunk from the zero
+             state first, one all_gather, compose, run again (2 passes on ranks >= 1; exact, no truncation).
+      chain  engines that can do neither (FIR, designs off the scan path): rank r waits for rank r-1's true end
+             state (send/recv); exact and serial.
     """
     import torch
     import torch.distributed as dist
@@ -159,10 +210,14 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None):
     rank = dist.get_rank(group)
     if world == 1:
         return engine(x_local, out_local, stream)
+    lens, mode = _plan(engine, x_local.numel(), world, rank, group, total)
 
-    # gloo (the CPU tests, or a rehearsal with several ranks on one GPU) moves host tensors only:
-    # stage the few doubles of the hand-off through the host there; RCCL takes the device tensors.
+    # gloo (the CPU tests, or a rehearsal with several ranks on one GPU) moves host tensors only: the few doubles
+    # of the hand-off are staged through the host there (which synchronises); RCCL takes the device tensors, and
+    # the collectives are enqueued on the caller's stream like the kernels around them.
     host_hop = dist.get_backend(group) == "gloo"
+    on_gpu = x_local.is_cuda
+    ctx = torch.cuda.stream(stream) if (on_gpu and stream is not None and hasattr(stream, "cuda_stream")) else _Null()
 
     def wire(t):
         return t.cpu() if (host_hop and t.is_cuda) else t
@@ -170,29 +225,91 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None):
     def peer(r):
         return dist.get_global_rank(group, r) if group is not None else r
 
-    pack = engine.new_pack()
-    ok = engine.tail_state(x_local, pack, stream) if x_local.numel() else False
-    flag = wire(torch.tensor([1 if ok else 0], dtype=torch.int32, device=pack.device))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
-        mine = wire(pack)
-        packs = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(packs, mine, group=group)
-        if rank > 0:
-            engine.import_state(packs[rank - 1].to(pack.device), stream)
-        out = engine(x_local, out_local, stream)
-    else:
-        if rank > 0:
-            got = wire(pack)
-            dist.recv(got, src=peer(rank - 1), group=group)
-            engine.import_state(got.to(pack.device), stream)
-        out = engine(x_local, out_local, stream)
-        if rank < world - 1:
-            engine.export_state(pack, stream)
-            dist.send(wire(pack), dst=peer(rank + 1), group=group)
-    # everyone ends with the stream's end state (the last rank's true state)
-    engine.export_state(pack, stream)
-    last = wire(pack)
-    dist.broadcast(last, src=peer(world - 1), group=group)
-    engine.import_state(last.to(pack.device), stream)
+    def gather(mine):
+        """(world, *mine.shape) tensor on mine's device"""
+        m = wire(mine.contiguous())
+        parts = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(parts, m, group=group)
+        return torch.stack(parts).to(mine.device)
+
+    carried_remote = bool(engine.__dict__.get("_carry_on_last_rank", False))
+    plen = engine.new_pack().numel()
+    with ctx:
+        if mode == "tail":
+            pack2 = torch.zeros((2, plen), dtype=torch.float64, device=engine.new_pack().device)
+            engine.export_state(pack2[1], stream)                   # my state at entry (the last rank's matters)
+            if rank < world - 1:
+                ok = engine.tail_state(x_local, pack2[0], stream)
+                assert ok, "tail hand-off planned but refused by the engine"
+            everyone = gather(pack2)
+            if rank == 0:
+                if carried_remote:
+                    engine.import_state(everyone[world - 1, 1], stream)
+            else:
+                engine.import_state(everyone[rank - 1, 0], stream)
+            out = engine(x_local, out_local, stream)
+        elif mode == "exact":
+            pack = engine.new_pack()
+            if carried_remote:                                      # rank 0 needs its start state before its pass
+                engine.export_state(pack, stream)
+                last = wire(pack)
+                dist.broadcast(last, src=peer(world - 1), group=group)
+                if rank == 0:
+                    engine.import_state(last.to(pack.device), stream)
+            if rank == 0:
+                out = engine(x_local, out_local, stream)            # true pass; the vector is the true end state
+                engine.export_state(pack, stream)
+            elif rank < world - 1:
+                engine.zero_state(stream)
+                out = engine(x_local, out_local, stream)            # zero-state pass: its end state is v_r
+                engine.export_state(pack, stream)
+            else:
+                out = out_local
+                pack.zero_()
+            everyone = gather(pack)
+            if rank > 0:
+                engine.compose_state(everyone, rank, lens[1], stream)
+                out = engine(x_local, out, stream)
+        else:
+            pack = engine.new_pack()
+            if carried_remote:
+                engine.export_state(pack, stream)
+                last = wire(pack)
+                dist.broadcast(last, src=peer(world - 1), group=group)
+                if rank == 0:
+                    engine.import_state(last.to(pack.device), stream)
+            if rank > 0:
+                got = wire(pack)
+                dist.recv(got, src=peer(rank - 1), group=group)
+                engine.import_state(got.to(pack.device), stream)
+            out = engine(x_local, out_local, stream)
+            if rank < world - 1:
+                engine.export_state(pack, stream)
+                dist.send(wire(pack), dst=peer(rank + 1), group=group)
+    engine.__dict__["_carry_on_last_rank"] = True
     return out
+
+
+def sync_end_state(engine, group=None, stream=None):
+    """After split_update: give every rank's engine the stream's end state (the last rank's), e.g. before the
+    stream is partitioned differently or handed to single-GPU code.  One broadcast of pack_len doubles."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    host_hop = dist.get_backend(group) == "gloo"
+    pack = engine.new_pack()
+    engine.export_state(pack, stream)
+    last = pack.cpu() if (host_hop and pack.is_cuda) else pack
+    src = dist.get_global_rank(group, world - 1) if group is not None else world - 1
+    dist.broadcast(last, src=src, group=group)
+    engine.import_state(last.to(pack.device), stream)
+    engine.__dict__["_carry_on_last_rank"] = False
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

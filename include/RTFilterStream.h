@@ -13,10 +13,12 @@
  * sub-chunk c is the zero-state response of the M samples in front of it, where M is the design's
  * decay length: the smallest power of two with max|A^M| < 2^-80 for the homogeneous recurrence
  * s' = A s of RTIIRFilter_update (ref: src/RTFilter.c:417-433).  What the truncation drops is
- * below 2^-80 of the state, far inside the 1e-12 bar.  Designs that do not decay within 2^20
- * samples, or fail the scan conditioning probe, or calls too short to split, run as a
- * one-channel RTFilterBank instead (correct, one workgroup: not time-parallel across the GPU).  FIR designs need none of this (their
- * bank kernels already split time) and go straight to a one-channel bank.
+ * below 2^-80 of the state, far inside the 1e-12 bar.  Designs that decay too slowly for that (or not within
+ * 2^20 samples) have their chunk maps composed exactly instead: a first pass from the zero state gives every
+ * sub-chunk's affine map s_end = A^Lc s_start + v, the start states follow by composition, a second pass filters
+ * (twice the traffic).  Designs that fail the scan conditioning probe, in-place calls without decay and calls too
+ * short to split run as a one-channel RTFilterBank (correct, one workgroup).  FIR designs need none of this
+ * (their bank kernels already split time) and go straight to a one-channel bank.
  *
  * Across GPUs (one process per GPU, rank r owns samples [r L, (r+1) L)): every rank but the last
  * computes RTFilterStream_tail_state of its own chunk -- the state hand-off vector, N+3 doubles --
@@ -77,6 +79,22 @@ EXPORT int RTFilterStream_import_state(RTFilterStream *stream, const double *pac
  * caller must then chain the ranks one after another with export/import of the true end state. */
 EXPORT int RTFilterStream_tail_state(RTFilterStream *stream, const double *in, size_t n,
                                      double *pack_dev, void *hip_stream);
+
+/* ---- exact composition of chunk maps (no decay assumption) ----------------------
+ * A chunk of L samples maps the state affinely: s_end = A^L s_start + v, v = the chunk's end state when it
+ * starts from zero.  RTFilterStream_updaten uses this across its sub-chunks when the design does not decay
+ * fast enough for the shortcut above (twice the traffic, still C-fold parallel).  Across ranks:
+ *   rank 0         runs its chunk from the stream's state; its hand-off vector is its true end state;
+ *   rank r >= 1    _zero_state, _updaten on its chunk (outputs to be overwritten), _export_state = v_r;
+ *   all_gather of the vectors;
+ *   rank r >= 1    _compose_state(packs, stride, r, L): state = A^L( ... A^L(A^L p_0 + p_1) + p_2 ... ) + p_(r-1)
+ *                  for the r vectors p_0 .. p_(r-1) of the ranks before it (chunks 1 .. r-1 of L samples each),
+ *                  then _updaten on its chunk again, now from the true start state.
+ * _exact_split: 1 if the design qualifies (IIR, na == nb <= 17, passes the conditioning probe). */
+EXPORT int RTFilterStream_exact_split(const RTFilterStream *stream);
+EXPORT int RTFilterStream_zero_state(RTFilterStream *stream, void *hip_stream);
+EXPORT int RTFilterStream_compose_state(RTFilterStream *stream, const double *packs_dev, size_t stride,
+                                        size_t count, size_t chunk_len, void *hip_stream);
 
 /* Host access to the carried state (state_ld doubles, see RTFilterStream_pack_len() - 2). */
 EXPORT int RTFilterStream_get_state(RTFilterStream *stream, double *state, double *fval, int32_t *init,

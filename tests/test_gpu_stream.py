@@ -160,7 +160,48 @@ def test_stream_from_filter_and_sync_to_host(G):
     fs.close()
 
 
-def _rank_worker(rank, world, port, n, q):
+def _resonator(radius=0.9999, theta=0.3 * np.pi):
+    """Second-order resonator with its pole pair at `radius`: well conditioned (passes the scan probe) and slow to
+    forget -- radius^M < 2^-80 needs M = 5.5e5 samples, so the decay shortcut cannot split a 2^24-sample call."""
+    b = np.array([(1.0 - radius) * 0.5, 0.0, -(1.0 - radius) * 0.5])
+    a = np.array([1.0, -2.0 * radius * np.cos(theta), radius * radius])
+    return b, a
+
+
+def test_slow_decay_design_is_split_by_composing_chunk_maps(G):
+    """A design that does not forget within a sub-chunk: the chunk maps s_end = A^L s_start + v are composed
+    exactly (no truncation) instead of running the stream as one workgroup.  2^24 samples in one call and a second,
+    ragged call that continues it, <= 1e-12 of the oracle relative to the output peak, state included."""
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    b, a = _resonator()
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    assert fs.exact_split and (fs.decay_length == 0 or fs.decay_length >= (1 << 19))
+    ref = orc.iir(b, a)
+    pos = 0
+    for n, want_split in (((1 << 24), 8), ((1 << 22) + 12345, 8)):
+        x = util.synth(77, 0, pos, n)
+        y = fs(torch.from_numpy(x).cuda()).cpu().numpy()
+        want = ref.updaten(x)
+        assert fs.last_split >= want_split, fs.last_split
+        assert np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+        st, fv, ini = fs.get_state()
+        assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+        assert ini == 0
+        pos += n
+    # reset: the next call is fresh again (sample 0 goes to stable_init) and is still split
+    fs.reset()
+    ref.reset()
+    x = util.synth(78, 0, 0, 1 << 21)
+    y = fs(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = ref.updaten(x)
+    assert fs.last_split >= 8 and np.max(np.abs(y - want)) <= TOL * np.max(np.abs(want))
+    fs.close()
+
+
+def _rank_worker(rank, world, port, n, q, design="bw8"):
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -172,17 +213,18 @@ def _rank_worker(rank, world, port, n, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        b, a = _bw8()
+        b, a = _bw8() if design == "bw8" else _resonator()
         fs = gstream.FilterStream(gbank.iir_design(b, a), device=0)
         outs = []
         for blk in range(2):
             lo, hi = gstream.time_range(n, world, rank)
             x = torch.from_numpy(util.synth(21, 0, blk * n + lo, hi - lo)).cuda()
-            y = gstream.split_update(fs, x)
+            y = gstream.split_update(fs, x, total=n if blk else None)    # with and without the static plan
             torch.cuda.synchronize()
             parts = [None] * world
             dist.all_gather_object(parts, y.cpu().numpy())
             outs.append(np.concatenate(parts))
+        gstream.sync_end_state(fs)
         st = fs.get_state()[0]
         if rank == 0:
             q.put((np.concatenate(outs), st))
@@ -191,26 +233,28 @@ def _rank_worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_split_the_stream(G):
-    """Rehearsal of the multi-GPU leg: two processes (gloo for the hand-off, both on cuda:0) each own
-    half of every block of the stream; the result equals one long run of the reference."""
+@pytest.mark.parametrize("design,world", [("bw8", 2), ("resonator", 3)], ids=["tail-handoff", "composed-maps"])
+def test_ranks_on_one_gpu_split_the_stream(G, design, world):
+    """Rehearsal of the multi-GPU leg: several processes (gloo for the hand-off, all on cuda:0) each own one
+    contiguous chunk of every block of the stream; the result equals one long run of the reference.  The
+    16th-order band-pass hands over the decay tail (one all_gather); the slow resonator composes chunk maps."""
     import socket
     import torch.multiprocessing as mp
     from oracle import oracle as orc
-    n, world = (1 << 20) + 4096, 2
+    n = (1 << 20) + 4096
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, n, q, design)) for r in range(world)]
     for p in procs:
         p.start()
     got, st = q.get(timeout=100)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    b, a = _bw8()
+    b, a = _bw8() if design == "bw8" else _resonator()
     ref = orc.iir(b, a)
     want = ref.updaten(util.synth(21, 0, 0, 2 * n))
     assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))

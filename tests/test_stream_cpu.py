@@ -34,7 +34,30 @@ class OracleEngine:
         self._orc = orc
         self.b, self.a = b, a
         self.f = orc.iir(b, a)
-        self.decay = decay                    # 0: tail shortcut unavailable -> ranks chain
+        self.decay = abs(decay)               # 0: no tail shortcut
+        self.decay_length = self.decay
+        self.exact_split = decay == 0         # decay 0 -> chunk maps composed; decay < 0 -> neither: ranks chain
+        if decay < 0:
+            self.decay = self.decay_length = 0
+
+    def zero_state(self, stream=None):
+        self.f.state[:] = 0.0
+        self.f.filtered_value = 0.0
+        self.f.initialized = 0
+
+    def compose_state(self, packs, count, chunk_len, stream=None):
+        """s = A^L( ... (A^L p_0 + p_1) ... ) + p_(count-1): A^L applied by running L zero samples (x = 0 gives
+        s' = A s exactly as the kernels' matrix does up to rounding)."""
+        s = packs[0, :-2].numpy().copy()
+        for j in range(1, count):
+            h = self._orc.iir(self.b, self.a)
+            h.initialized = 0
+            h.state[:] = s
+            h.updaten(np.zeros(chunk_len))
+            s = h.state + packs[j, :-2].numpy()
+        self.f.state[:] = s
+        self.f.filtered_value = float(packs[count - 1, -2])
+        self.f.initialized = 0
 
     def new_pack(self):
         import torch
@@ -87,6 +110,7 @@ def _worker(rank, world, port, n, decay, q):
             parts = [None] * world
             dist.all_gather_object(parts, y.numpy())
             outs.append(np.concatenate(parts))
+        gstream.sync_end_state(eng)
         snap = eng.f.snapshot()
         states = [None] * world
         dist.all_gather_object(states, snap["state"])
@@ -96,12 +120,12 @@ def _worker(rank, world, port, n, decay, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("decay", [1024, 0], ids=["tail-handoff", "chained"])
+@pytest.mark.parametrize("decay", [1024, 0, -1], ids=["tail-handoff", "composed", "chained"])
 def test_two_gloo_ranks_split_one_stream_in_time(decay):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
     from tests import util
-    n, world = 3 * 4096 + 777, 2
+    n, world = 3 * 4096 + 777, 3 if decay == 0 else 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -117,7 +141,7 @@ def test_two_gloo_ranks_split_one_stream_in_time(decay):
     _, b, a = util.design_coefs("bw4_bp_0.3_0.6")
     ref = orc.iir(b, a)
     want = ref.updaten(util.synth(7, 0, 0, 2 * n))
-    if decay == 0:
+    if decay < 0:
         assert util.bits_equal(got, want)                       # chained hand-off of the true state: exact
         assert all(util.bits_equal(s, ref.state) for s in states)
     else:
