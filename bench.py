@@ -131,9 +131,15 @@ def main():
     ap.add_argument("--stream-log2", type=int, default=30)
     ap.add_argument("--mixed-channels", type=int, default=65536,
                     help="config 4: channels per wave (SURVEY.md 8(d): 2^16)")
+    ap.add_argument("--mixed-total", type=int, default=1 << 20, help="config 4: channels of the whole bank (2^20)")
     ap.add_argument("--mixed-layout", choices=["sorted", "interleaved"], default="sorted")
     ap.add_argument("--gather", action="store_true",
-                    help="config 4: all_gather every channel's filtered_value after each block (RCCL)")
+                    help="config 4: all_gather one WAVE-SIZED output block per step over RCCL/xGMI (every rank "
+                         "contributes wave/N channels x 64K samples of the wave it just filtered; 32 GiB assembled "
+                         "on every rank), on its own stream, overlapped with the next wave's filtering; reports "
+                         "filter-only vs filter+gather and GB/s per xGMI link")
+    ap.add_argument("--gather-fval", action="store_true",
+                    help="config 4: all_gather one double per channel (the last output) after each block instead")
     ap.add_argument("--fir-channels", type=int, default=65536)
     ap.add_argument("--layout", choices=["blocks", "rows"], default="blocks",
                     help="config 2: how the resident 2^20-sample streams lie in HBM: `rows` = one row of 2^20 samples per "
@@ -153,7 +159,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # the latter: RCCL code path with ONE rank (tests)
         import torch.distributed as dist
         _init_dist(dist, local)
     torch.cuda.set_device(local)
@@ -325,7 +331,7 @@ def main_fir512(args, emit=True):
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # the latter: RCCL code path with ONE rank (tests)
         import torch.distributed as dist
         _init_dist(dist, local)
     torch.cuda.set_device(local)
@@ -418,7 +424,7 @@ def main_mixed(args):
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # the latter: RCCL code path with ONE rank (tests)
         import torch.distributed as dist
         _init_dist(dist, local)
     torch.cuda.set_device(local)
@@ -432,7 +438,7 @@ def main_mixed(args):
         return gbank.fir_design(b) if kind != "iir" else gbank.iir_design(b, a)
 
     wave = args.mixed_channels                       # channels per wave (2^16)
-    total = 1 << 20
+    total = args.mixed_total
     per_rank = total // world
     nwaves = max(1, per_rank // wave)
     banks, kinds = [], []
@@ -451,25 +457,54 @@ def main_mixed(args):
             kinds.append("interleaved")
         order = list(range(len(banks)))
     pitch = BLOCK + 128
+    gather_rows = dist is not None and args.gather
+    nybuf = 2 if gather_rows else 1                  # the gather of wave w reads y while wave w+1 is written
     xbuf = torch.empty((wave, pitch), dtype=torch.float64, device=dev)
-    ybuf = torch.empty((wave, pitch), dtype=torch.float64, device=dev)
-    x, y = xbuf[:, :BLOCK], ybuf[:, :BLOCK]
+    ybufs = [torch.empty((wave, pitch), dtype=torch.float64, device=dev) for _ in range(nybuf)]
+    x = xbuf[:, :BLOCK]
     gbank.synth_fill(x, 0x5EED0004, chan0=rank * per_rank, n0=0)
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
-    fv_all = torch.empty(world * wave, dtype=torch.float64, device=dev) if (dist is not None and args.gather) else None
+    fv_all = (torch.empty(world * wave, dtype=torch.float64, device=dev)
+              if (dist is not None and args.gather_fval) else None)
+    slice_rows = wave // world                       # this rank's contribution to the wave-sized gather
+    gathered = gstream_g = None
+    g_events, y_free = [], [None, None]
+    if gather_rows:
+        from dsp_amd import shard
+        gathered = torch.empty((world * slice_rows, BLOCK), dtype=torch.float64, device=dev)
+        send = torch.empty((slice_rows, BLOCK), dtype=torch.float64, device=dev)
+        gstream_g = torch.cuda.Stream(device=dev)
     step_no = [0]
 
     def step(ev=None):
-        bank = banks[order[step_no[0] % len(order)]]
+        k = step_no[0]
+        bank = banks[order[k % len(order)]]
+        ybuf = ybufs[k % nybuf]
         step_no[0] += 1
+        if gather_rows and y_free[k % nybuf] is not None:
+            stream.wait_event(y_free[k % nybuf])     # the gather that read this buffer two steps ago is done
         if ev is not None:
             ev[0].record(stream)
-        bank.updaten_ptr(y.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
+        bank.updaten_ptr(ybuf.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
         if ev is not None:
             ev[1].record(stream)
         if fv_all is not None:
-            dist.all_gather_into_tensor(fv_all, y[:, BLOCK - 1].contiguous())
+            dist.all_gather_into_tensor(fv_all, ybuf[:, BLOCK - 1].contiguous())
+        if gather_rows:
+            done = torch.cuda.Event()
+            done.record(stream)
+            with torch.cuda.stream(gstream_g):
+                gstream_g.wait_event(done)
+                g0 = torch.cuda.Event(enable_timing=True)
+                g1 = torch.cuda.Event(enable_timing=True)
+                g0.record(gstream_g)
+                send.copy_(ybuf[:slice_rows, :BLOCK])              # dense rows for the collective
+                shard.gather_rows_into(gathered, send)
+                g1.record(gstream_g)
+                if ev is not None:
+                    g_events.append((g0, g1))
+                y_free[k % nybuf] = g1
 
     for _ in range(args.warmup):
         step()
@@ -505,12 +540,13 @@ def main_mixed(args):
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 4: 2^20-channel mixed bank (%s) x 64K samples, channel-sharded, waves of %d "
-                                   "channels" % ("2^19 IIR order 8 + 2^19 FIR 32 taps, sorted by type"
+            "config": {"workload": "config 4: %d-channel mixed bank (%s) x 64K samples, channel-sharded, waves of %d "
+                                   "channels" % (total, "2^19 IIR order 8 + 2^19 FIR 32 taps, sorted by type"
                                                  if args.mixed_layout == "sorted" else
                                                  "IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved", wave),
                        "channels_per_gpu": per_rank, "wave_channels": wave, "waves_per_gpu": nwaves, "block": BLOCK,
-                       "row_pitch_doubles": pitch, "kernel": args.mode, "gather": bool(fv_all is not None),
+                       "row_pitch_doubles": pitch, "kernel": args.mode,
+                       "gather": "rows" if gather_rows else ("filtered_value" if fv_all is not None else None),
                        "rank0_wave_ms": {k: float(np.mean(v)) for k, v in per_kind.items()},
                        "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -519,6 +555,22 @@ def main_mixed(args):
                          "note": "all kernels of one RTFilterBank_updaten over one wave, rank 0's device time per call",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
+        if gather_rows and g_events:
+            g_ms = np.array([g0.elapsed_time(g1) for g0, g1 in g_events])
+            recv = (world - 1) * slice_rows * BLOCK * 8                      # bytes this rank receives per gather
+            line["gather"] = {
+                "what": "all_gather (RCCL) of one wave-sized block per step: every rank contributes %d channels x 64K "
+                        "samples (%.2f GiB) of the wave it just filtered, %.2f GiB assembled on every rank; own stream, "
+                        "overlapped with the next wave's filtering" % (slice_rows, slice_rows * BLOCK * 8 / 2 ** 30,
+                                                                        world * slice_rows * BLOCK * 8 / 2 ** 30),
+                "gather_ms_avg": float(np.mean(g_ms)), "filter_ms_avg": avg_s * 1e3,
+                "filter_plus_gather_ms_per_step": elapsed / args.steps * 1e3,
+                "filter_only_msamples_s": world * samples / avg_s / 1e6,
+                "filter_plus_gather_msamples_s": world * samples * args.steps / elapsed / 1e6,
+                "bytes_received_per_rank": recv,
+                "xgmi_gbs_per_rank": recv / (float(np.mean(g_ms)) / 1e3) / 1e9 if world > 1 else None,
+                "xgmi_gbs_per_link": recv / (float(np.mean(g_ms)) / 1e3) / 1e9 / 7 if world > 1 else None,
+            }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -535,7 +587,7 @@ def main_stream16(args, emit=True):
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("BENCH_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # the latter: RCCL code path with ONE rank (tests)
         import torch.distributed as dist
         _init_dist(dist, local)
     torch.cuda.set_device(local)

@@ -30,8 +30,21 @@ def gather_rows(local_rows, nch, group=None):
     ranges = all_ranges(nch, world)
     biggest = max(hi - lo for lo, hi in ranges)
     n = local_rows.shape[1]
+    if nch % world == 0 and local_rows.is_contiguous():
+        # equal shards: one collective straight into the result, no padding or reassembly copies
+        full = torch.empty((nch, n), dtype=local_rows.dtype, device=local_rows.device)
+        dist.all_gather_into_tensor(full, local_rows, group=group)
+        return full
     padded = torch.zeros((biggest, n), dtype=local_rows.dtype, device=local_rows.device)
     padded[: local_rows.shape[0]] = local_rows
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(ranges)], dim=0)
+
+
+def gather_rows_into(full, local_rows, group=None):
+    """Equal shards only: all_gather of (rows, n) blocks into the preallocated (world*rows, n) tensor `full`
+    (no allocation: what a streaming consumer calls once per wave).  Enqueued on torch's current stream."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(full, local_rows, group=group)
+    return full
