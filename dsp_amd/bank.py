@@ -170,6 +170,20 @@ class FilterBank:
         _check(dspdll.RTFilterBank_updaten_noalloc(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
                                                    ld_in, n, _stream_ptr(stream, self.device)), "RTFilterBank_updaten_noalloc")
 
+    def filter_host(self, x, out=None):
+        """x: (nch, n) float64 numpy array in host memory (rows contiguous): RTFilterBank_updaten_host, the
+        reference's per-filter call on host arrays, staged through pinned rings.  Returns `out`."""
+        x = np.asarray(x)
+        assert x.dtype == np.float64 and x.ndim == 2 and x.shape[0] == self.nch and x.strides[1] == 8
+        if out is None:
+            out = np.empty_like(x)
+        assert out.shape == x.shape and out.dtype == np.float64 and out.strides[1] == 8
+        dp = C.POINTER(C.c_double)
+        _check(dspdll.RTFilterBank_updaten_host(self._handle, out.ctypes.data_as(dp), out.strides[0] // 8,
+                                                x.ctypes.data_as(dp), x.strides[0] // 8, x.shape[1]),
+               "RTFilterBank_updaten_host")
+        return out
+
     def __call__(self, x, out=None, stream=None):
         """x: (nch, n) float64 device tensor with contiguous rows.  Returns the output tensor."""
         import torch
@@ -224,3 +238,54 @@ def synth_fill(tensor, seed, chan0=0, n0=0, stream=None):
     _check(dspdll.dsp_synth_fill(C.c_void_p(tensor.data_ptr()), tensor.stride(0), nch, n, seed, chan0, n0,
                                  _stream_ptr(stream, tensor.device)), "dsp_synth_fill")
     return tensor
+
+
+class BankFeed:
+    """RTFilterBankFeed: frames (one sample per channel) in, filtered frames out, coalesced into device blocks --
+    the bank-wide form of the reference's per-sample RTFilter_update / FilterIterator (python/dsp.py:6-13,35-38)."""
+
+    def __init__(self, bank, block_frames):
+        self._h = C.c_void_p()
+        self.bank = bank
+        self.nch = bank.nch
+        _check(dspdll.RTFilterBankFeed_create(C.byref(self._h), bank._handle, block_frames), "RTFilterBankFeed_create")
+
+    def close(self):
+        if self._h:
+            dspdll.RTFilterBankFeed_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, frames):
+        """frames: (nframes, nch) float64, C-contiguous (or one frame of nch values)."""
+        frames = np.ascontiguousarray(np.atleast_2d(frames), dtype=np.float64)
+        assert frames.shape[1] == self.nch
+        took = C.c_size_t()
+        _check(dspdll.RTFilterBankFeed_push(self._h, frames.ctypes.data_as(C.POINTER(C.c_double)), frames.shape[0],
+                                            C.byref(took)), "RTFilterBankFeed_push")
+        return took.value                    # < len(frames): two blocks wait to be popped; pop, then push the rest
+
+    def pop(self, max_frames, wait=False):
+        """Filtered frames that are back (at most max_frames), oldest first; wait=True blocks until the oldest
+        submitted block has come back."""
+        if wait:
+            _check(dspdll.RTFilterBankFeed_wait(self._h), "RTFilterBankFeed_wait")
+        out = np.empty((max_frames, self.nch), dtype=np.float64)
+        got = C.c_size_t()
+        _check(dspdll.RTFilterBankFeed_pop(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), max_frames,
+                                           C.byref(got)), "RTFilterBankFeed_pop")
+        return out[: got.value]
+
+    def available(self):
+        return dspdll.RTFilterBankFeed_available(self._h)
+
+    def pending(self):
+        return dspdll.RTFilterBankFeed_pending(self._h)
+
+    def flush(self):
+        _check(dspdll.RTFilterBankFeed_flush(self._h), "RTFilterBankFeed_flush")

@@ -173,6 +173,15 @@ _proto("RTFilterBank_updaten", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c
 _proto("RTFilterBank_updaten_noalloc", c_int,
        [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterBank_noalloc_max_doubles", c_size_t, [])
+_proto("RTFilterBank_updaten_host", c_int, [c_void_p, _dp, c_size_t, _dp, c_size_t, c_size_t])
+_proto("RTFilterBankFeed_create", c_int, [POINTER(c_void_p), c_void_p, c_size_t])
+_proto("RTFilterBankFeed_destroy", None, [c_void_p])
+_proto("RTFilterBankFeed_push", c_int, [c_void_p, _dp, c_size_t, POINTER(c_size_t)])
+_proto("RTFilterBankFeed_pop", c_int, [c_void_p, _dp, c_size_t, POINTER(c_size_t)])
+_proto("RTFilterBankFeed_available", c_size_t, [c_void_p])
+_proto("RTFilterBankFeed_flush", c_int, [c_void_p])
+_proto("RTFilterBankFeed_wait", c_int, [c_void_p])
+_proto("RTFilterBankFeed_pending", c_size_t, [c_void_p])
 _proto("RTFilterBank_reset", c_int, [c_void_p, c_void_p])
 _proto("RTFilterBank_sync_to_host", c_int, [c_void_p, c_void_p])
 _proto("RTFilterBank_state_ld", c_size_t, [c_void_p])

@@ -203,7 +203,7 @@ int pool_alloc(void **out, size_t bytes, int device)
  * an event recorded there now gates its reuse (pool_alloc passes it over until the event has completed).
  * Without `ordered` the caller vouches that the device is done with the block (the bank's own frees come after
  * a stream or device synchronisation). */
-int pool_free(void *ptr, bool ordered = false, hipStream_t stream = nullptr)
+int pool_free(void *ptr, bool ordered, hipStream_t stream)
 {
     if (!ptr) return RTFB_OK;
     Pool &p = pool();
@@ -232,6 +232,166 @@ int pool_free(void *ptr, bool ordered = false, hipStream_t stream = nullptr)
     p.cache[{blk.device, blk.bytes}].push_back({ptr, ready});
     return RTFB_OK;
 }
+
+/* ------------------------------------------------------------------------ */
+/* host streaming: pinned staging rings around the device path                */
+
+/* Two pinned host buffers and two device buffers each way, three streams.  Chunk k: the CPU stages the caller's
+ * rows into pinned in[k&1] (while the GPU still works on chunk k-1), H2D on s_in, the filter on s_run (in order:
+ * the state carries), D2H into pinned out[k&1] on s_out, and the CPU copies chunk k-1's pinned output to the
+ * caller's rows meanwhile.  Pageable memory never meets the DMA engines, which then run at link speed. */
+struct HostPipe {
+    int device = -1;
+    size_t bytes = 0;                        /* capacity of every buffer */
+    double *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+    double *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t e_h2d[2] = {nullptr, nullptr}, e_run[2] = {nullptr, nullptr}, e_d2h[2] = {nullptr, nullptr};
+    bool ready() const { return bytes != 0; }
+};
+
+int pool_alloc(void **out, size_t bytes, int device);
+int pool_free(void *ptr, bool ordered = false, hipStream_t stream = nullptr);
+
+void host_pipe_release(HostPipe &hp)
+{
+    if (hp.device < 0) return;
+    DeviceScope ds(hp.device);
+    if (hp.s_in) (void)hipStreamSynchronize(hp.s_in);
+    if (hp.s_run) (void)hipStreamSynchronize(hp.s_run);
+    if (hp.s_out) (void)hipStreamSynchronize(hp.s_out);
+    for (int k = 0; k < 2; ++k) {
+        if (hp.h_in[k]) (void)hipHostFree(hp.h_in[k]);
+        if (hp.h_out[k]) (void)hipHostFree(hp.h_out[k]);
+        if (hp.d_in[k]) (void)pool_free(hp.d_in[k], false, nullptr);
+        if (hp.d_out[k]) (void)pool_free(hp.d_out[k], false, nullptr);
+        if (hp.e_h2d[k]) (void)hipEventDestroy(hp.e_h2d[k]);
+        if (hp.e_run[k]) (void)hipEventDestroy(hp.e_run[k]);
+        if (hp.e_d2h[k]) (void)hipEventDestroy(hp.e_d2h[k]);
+    }
+    if (hp.s_in) (void)hipStreamDestroy(hp.s_in);
+    if (hp.s_run) (void)hipStreamDestroy(hp.s_run);
+    if (hp.s_out) (void)hipStreamDestroy(hp.s_out);
+    hp = HostPipe();
+}
+
+/* All or nothing: resources are built into a local pipe and committed only when every one of them exists
+ * (a half-built pipe is never left behind for the next call to trip over). */
+int host_pipe_prepare(HostPipe &hp, int device, size_t bytes)
+{
+    if (hp.ready() && hp.device == device && hp.bytes >= bytes) return RTFB_OK;
+    host_pipe_release(hp);
+    HostPipe np;
+    np.device = device;
+    int rc = RTFB_OK;
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail_hip(e, what);
+        return e == hipSuccess;
+    };
+    hipok(hipStreamCreateWithFlags(&np.s_in, hipStreamNonBlocking), "hipStreamCreate") &&
+        hipok(hipStreamCreateWithFlags(&np.s_run, hipStreamNonBlocking), "hipStreamCreate") &&
+        hipok(hipStreamCreateWithFlags(&np.s_out, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 2 && !rc; ++k) {
+        hipok(hipEventCreateWithFlags(&np.e_h2d[k], hipEventDisableTiming), "hipEventCreate") &&
+            hipok(hipEventCreateWithFlags(&np.e_run[k], hipEventDisableTiming), "hipEventCreate") &&
+            hipok(hipEventCreateWithFlags(&np.e_d2h[k], hipEventDisableTiming), "hipEventCreate") &&
+            hipok(hipHostMalloc(reinterpret_cast<void **>(&np.h_in[k]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
+            hipok(hipHostMalloc(reinterpret_cast<void **>(&np.h_out[k]), bytes, hipHostMallocDefault), "hipHostMalloc");
+        void *p = nullptr;
+        if (!rc && !(rc = pool_alloc(&p, bytes, device))) np.d_in[k] = static_cast<double *>(p);
+        if (!rc && !(rc = pool_alloc(&p, bytes, device))) np.d_out[k] = static_cast<double *>(p);
+    }
+    if (rc) {
+        const std::string keep = t_last_error;
+        host_pipe_release(np);
+        t_last_error = keep;
+        return rc;
+    }
+    np.bytes = bytes;
+    hp = np;
+    return RTFB_OK;
+}
+
+/* Strided row copy on the host, split over a few threads when it is large (one thread moves ~6 GB/s, the link
+ * takes several times that). */
+void copy_rows_host(double *dst, size_t ld_dst, const double *src, size_t ld_src, size_t rows, size_t len)
+{
+    const size_t bytes = rows * len * sizeof(double);
+    size_t nthreads = std::min<size_t>({(size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency() / 2),
+                                        bytes >> 22});
+    if (nthreads <= 1) {
+        for (size_t r = 0; r < rows; ++r) std::memcpy(dst + r * ld_dst, src + r * ld_src, len * sizeof(double));
+        return;
+    }
+    /* split by rows when there are enough of them, else by columns of the one long row */
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nthreads; ++t) {
+        th.emplace_back([=]() {
+            if (rows >= nthreads) {
+                for (size_t r = rows * t / nthreads; r < rows * (t + 1) / nthreads; ++r)
+                    std::memcpy(dst + r * ld_dst, src + r * ld_src, len * sizeof(double));
+            } else {
+                const size_t c0 = len * t / nthreads, c1 = len * (t + 1) / nthreads;
+                for (size_t r = 0; r < rows; ++r)
+                    std::memcpy(dst + r * ld_dst + c0, src + r * ld_src + c0, (c1 - c0) * sizeof(double));
+            }
+        });
+    }
+    for (std::thread &x : th) x.join();
+}
+
+/* rows x n doubles between the caller's host arrays (row pitches ld_in / ld_out) and the device path, `nt`
+ * samples of every row per chunk.  filter(d_out, d_in, len, stream) advances all rows by `len` samples on
+ * dense device blocks of row pitch `len`.  Blocks until `out` is complete; on an error the streams are drained
+ * before returning (no copy is left in flight towards the caller's memory). */
+template <typename F>
+int host_pipe_run(HostPipe &hp, size_t rows, size_t n, const double *in, size_t ld_in, double *out, size_t ld_out,
+                  size_t nt, F &&filter)
+{
+    int rc = RTFB_OK;
+    auto chk = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail_hip(e, what);
+        return rc == RTFB_OK;
+    };
+    auto drain = [&](size_t k, size_t pos, size_t len) {          /* chunk k: pinned out -> caller */
+        const int slot = (int)(k & 1);
+        if (!chk(hipEventSynchronize(hp.e_d2h[slot]), "hipEventSynchronize")) return;
+        copy_rows_host(out + pos, ld_out, hp.h_out[slot], len, rows, len);
+    };
+    size_t k = 0, prev_pos = 0, prev_len = 0;
+    for (size_t pos = 0; pos < n && !rc; pos += nt, ++k) {
+        const size_t len = std::min(nt, n - pos);
+        const int slot = (int)(k & 1);
+        if (k >= 2 && !chk(hipEventSynchronize(hp.e_h2d[slot]), "hipEventSynchronize")) break;   /* pinned in[slot] is free */
+        copy_rows_host(hp.h_in[slot], len, in + pos, ld_in, rows, len);
+        if (k >= 2) chk(hipStreamWaitEvent(hp.s_in, hp.e_run[slot], 0), "hipStreamWaitEvent");
+        chk(hipMemcpyAsync(hp.d_in[slot], hp.h_in[slot], rows * len * sizeof(double), hipMemcpyHostToDevice, hp.s_in),
+            "hipMemcpyAsync");
+        chk(hipEventRecord(hp.e_h2d[slot], hp.s_in), "hipEventRecord");
+        chk(hipStreamWaitEvent(hp.s_run, hp.e_h2d[slot], 0), "hipStreamWaitEvent");
+        if (k >= 2) chk(hipStreamWaitEvent(hp.s_run, hp.e_d2h[slot], 0), "hipStreamWaitEvent");
+        if (!rc) rc = filter(hp.d_out[slot], hp.d_in[slot], len, hp.s_run);
+        chk(hipEventRecord(hp.e_run[slot], hp.s_run), "hipEventRecord");
+        chk(hipStreamWaitEvent(hp.s_out, hp.e_run[slot], 0), "hipStreamWaitEvent");
+        chk(hipMemcpyAsync(hp.h_out[slot], hp.d_out[slot], rows * len * sizeof(double), hipMemcpyDeviceToHost, hp.s_out),
+            "hipMemcpyAsync");
+        chk(hipEventRecord(hp.e_d2h[slot], hp.s_out), "hipEventRecord");
+        if (k >= 1 && !rc) drain(k - 1, prev_pos, prev_len);       /* overlaps the GPU's work on chunk k */
+        prev_pos = pos;
+        prev_len = len;
+    }
+    if (!rc && k >= 1) drain(k - 1, prev_pos, prev_len);
+    if (rc) {
+        const std::string keep = t_last_error;
+        (void)hipStreamSynchronize(hp.s_in);
+        (void)hipStreamSynchronize(hp.s_run);
+        (void)hipStreamSynchronize(hp.s_out);
+        t_last_error = keep;
+    }
+    return rc;
+}
+
+constexpr size_t kHostChunkBytes = (size_t)64 << 20;      /* per staging buffer */
 
 /* typed helper: pooled device array filled from a host vector */
 template <typename T>
@@ -321,6 +481,7 @@ struct RTFilterBank {
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
     double *d_static_scratch = nullptr;   /* this device's copy of `scratch` (RTFilterBank_updaten_noalloc) */
+    HostPipe host;                        /* staging rings of RTFilterBank_updaten_host, built on first use */
 };
 
 namespace {
@@ -1297,6 +1458,7 @@ void RTFilterBank_destroy(RTFilterBank *bank)
         DeviceScope ds(bank->device);
         (void)hipDeviceSynchronize();
     }
+    host_pipe_release(bank->host);
     free_bank_device(bank);
     delete bank;
 }
@@ -1422,6 +1584,30 @@ int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out,
 }
 
 size_t RTFilterBank_noalloc_max_doubles(void) { return kStaticScratchDoubles; }
+
+/* RTFilterBank_updaten on HOST arrays: for c: RTFilter_updaten(out + c*ld_out, filter_c, in + c*ld_in, n) as a
+ * caller of the reference makes it, moved through the GPU in chunks of time (all channels x nt samples, so that
+ * the carried state streams), through pinned staging rings.  Bounded by the host link and the CPU's copies. */
+int RTFilterBank_updaten_host(RTFilterBank *bank, double *out, size_t ld_out, const double *in, size_t ld_in, size_t n)
+{
+    if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten_host: NULL argument");
+    if (n == 0) return RTFB_OK;
+    if (bank->nch > 1 && (ld_in < n || ld_out < n))
+        return fail(RTFB_EINVAL, "RTFilterBank_updaten_host: ld smaller than n");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    /* chunk: all channels x nt samples in one staging buffer; whole 2048-sample segments when they fit */
+    size_t nt = kHostChunkBytes / sizeof(double) / bank->nch;
+    if (nt >= 2048) nt = nt / 2048 * 2048;
+    if (nt == 0) nt = 1;
+    nt = std::min(nt, n);
+    int rc = host_pipe_prepare(bank->host, bank->device, std::max(bank->nch * nt * sizeof(double), (size_t)4096));
+    if (rc) return rc;
+    return host_pipe_run(bank->host, bank->nch, n, in, ld_in, out, ld_out, nt,
+                         [&](double *d_out, const double *d_in, size_t len, hipStream_t s) {
+                             return RTFilterBank_updaten(bank, d_out, len, d_in, len, len, s);
+                         });
+}
 
 int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch, size_t n,
                   int threads, int seg, void *hip_stream)
@@ -1606,10 +1792,7 @@ struct RTFilterStream {
     bool exact_ok = false;                    /* chunk maps may be composed exactly (scan-safe fast IIR) */
     bool maybe_fresh = true;                  /* the next sample may go to the initialiser (host-side view) */
     std::map<size_t, double *> d_power;       /* chunk length L -> A^L (N x N, row-major) on the device */
-    /* RTFilterStream_updaten_host: two device chunk pairs and three streams, created on first use */
-    double *d_hin[2] = {nullptr, nullptr}, *d_hout[2] = {nullptr, nullptr};
-    hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    HostPipe host;                            /* staging rings of RTFilterStream_updaten_host, built on first use */
 };
 
 namespace {
@@ -1870,19 +2053,7 @@ void RTFilterStream_destroy(RTFilterStream *st)
     RTFilterBank_destroy(st->one);             /* synchronises the device */
     pool_free(st->d_scratch);
     for (auto &kv : st->d_power) pool_free(kv.second);
-    {
-        DeviceScope ds(st->device);
-        for (int k = 0; k < 2; ++k) {
-            pool_free(st->d_hin[k]);
-            pool_free(st->d_hout[k]);
-            if (st->ev_in[k]) (void)hipEventDestroy(st->ev_in[k]);
-            if (st->ev_run[k]) (void)hipEventDestroy(st->ev_run[k]);
-            if (st->ev_out[k]) (void)hipEventDestroy(st->ev_out[k]);
-        }
-        if (st->hs_in) (void)hipStreamDestroy(st->hs_in);
-        if (st->hs_run) (void)hipStreamDestroy(st->hs_run);
-        if (st->hs_out) (void)hipStreamDestroy(st->hs_out);
-    }
+    host_pipe_release(st->host);
     delete st;
 }
 
@@ -1947,45 +2118,13 @@ int RTFilterStream_updaten_host(RTFilterStream *st, double *out, const double *i
     if (!n) return RTFB_OK;
     DeviceScope ds(st->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
-    constexpr size_t kChunk = (size_t)1 << 23;             /* 64 MiB each way */
-    if (!st->hs_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&st->hs_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&st->hs_run, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&st->hs_out, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipEventCreateWithFlags(&st->ev_in[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&st->ev_run[k], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&st->ev_out[k], hipEventDisableTiming));
-            void *p = nullptr;
-            int rc = pool_alloc(&p, kChunk * sizeof(double), st->device);
-            if (rc) return rc;
-            st->d_hin[k] = static_cast<double *>(p);
-            rc = pool_alloc(&p, kChunk * sizeof(double), st->device);
-            if (rc) return rc;
-            st->d_hout[k] = static_cast<double *>(p);
-        }
-    }
-    /* chunk k: copy in on hs_in (after chunk k-2 left its input buffer), filter on hs_run (in order:
-     * the state carries), copy out on hs_out (the output buffer is reused after chunk k-2 went out) */
-    size_t k = 0;
-    for (size_t pos = 0; pos < n; pos += kChunk, ++k) {
-        const size_t len = std::min(kChunk, n - pos);
-        const int slot = (int)(k & 1);
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(st->hs_in, st->ev_run[slot], 0));
-        HIP_TRY(hipMemcpyAsync(st->d_hin[slot], in + pos, len * sizeof(double), hipMemcpyHostToDevice, st->hs_in));
-        HIP_TRY(hipEventRecord(st->ev_in[slot], st->hs_in));
-        HIP_TRY(hipStreamWaitEvent(st->hs_run, st->ev_in[slot], 0));
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(st->hs_run, st->ev_out[slot], 0));
-        int rc = RTFilterStream_updaten(st, st->d_hout[slot], st->d_hin[slot], len, st->hs_run);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(st->ev_run[slot], st->hs_run));
-        HIP_TRY(hipStreamWaitEvent(st->hs_out, st->ev_run[slot], 0));
-        HIP_TRY(hipMemcpyAsync(out + pos, st->d_hout[slot], len * sizeof(double), hipMemcpyDeviceToHost, st->hs_out));
-        HIP_TRY(hipEventRecord(st->ev_out[slot], st->hs_out));
-    }
-    HIP_TRY(hipStreamSynchronize(st->hs_out));
-    HIP_TRY(hipStreamSynchronize(st->hs_run));
-    return RTFB_OK;
+    const size_t nt = std::min(n, kHostChunkBytes / sizeof(double));      /* 2^23 samples per chunk */
+    int rc = host_pipe_prepare(st->host, st->device, std::max(nt * sizeof(double), (size_t)4096));
+    if (rc) return rc;
+    return host_pipe_run(st->host, 1, n, in, n, out, n, nt,
+                         [&](double *d_out, const double *d_in, size_t len, hipStream_t s) {
+                             return RTFilterStream_updaten(st, d_out, d_in, len, s);
+                         });
 }
 
 int RTFilterStream_reset(RTFilterStream *st, void *hip_stream)
@@ -2102,6 +2241,196 @@ int RTFilterStream_set_state(RTFilterStream *st, const double *state, const doub
     if (!st) return fail(RTFB_EINVAL, "NULL stream");
     st->maybe_fresh = true;
     return RTFilterBank_set_state(st->one, state, fval, init, hip_stream);
+}
+
+}  /* extern "C" */
+
+/* ======================================================================== */
+/* RTFilterBankFeed: per-sample producers coalesced into device blocks         */
+/* (the reference's per-sample entry is one FFI        */
+/* crossing and one filter per call: src/RTFilter.c:98-108, python/dsp.py:6-13,35-38) */
+
+struct RTFilterBankFeed {
+    RTFilterBank *bank = nullptr;
+    size_t nch = 0, block = 0;               /* frames per device block */
+    hipStream_t s = nullptr;
+    double *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};      /* pinned, time-major [block][nch] */
+    double *d_tm = nullptr, *d_cm = nullptr;                                   /* device: time-major, channel-major */
+    hipEvent_t done[2] = {nullptr, nullptr};
+    size_t fill = 0;                         /* frames in the buffer being filled */
+    int fill_slot = 0;
+    /* blocks submitted and not yet popped, oldest first (at most 2): slot, frames, frames already popped */
+    struct InFlight { int slot; size_t frames, popped; };
+    std::deque<InFlight> queue;
+};
+
+namespace {
+
+void feed_release(RTFilterBankFeed *f)
+{
+    DeviceScope ds(f->bank->device);
+    if (f->s) (void)hipStreamSynchronize(f->s);
+    for (int k = 0; k < 2; ++k) {
+        if (f->h_in[k]) (void)hipHostFree(f->h_in[k]);
+        if (f->h_out[k]) (void)hipHostFree(f->h_out[k]);
+        if (f->done[k]) (void)hipEventDestroy(f->done[k]);
+    }
+    pool_free(f->d_tm);
+    pool_free(f->d_cm);
+    if (f->s) (void)hipStreamDestroy(f->s);
+}
+
+/* the block in `fill_slot` goes to the device: H2D, frames -> rows, filter in place, rows -> frames, D2H */
+int feed_submit(RTFilterBankFeed *f)
+{
+    const size_t frames = f->fill;
+    if (!frames) return RTFB_OK;
+    const int slot = f->fill_slot;
+    const size_t bytes = frames * f->nch * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(f->d_tm, f->h_in[slot], bytes, hipMemcpyHostToDevice, f->s));
+    HIP_TRY(launch_transpose(f->d_cm, f->block, f->d_tm, f->nch, frames, f->nch, f->s));
+    int rc = RTFilterBank_updaten(f->bank, f->d_cm, f->block, f->d_cm, f->block, frames, f->s);
+    if (rc) return rc;
+    HIP_TRY(launch_transpose(f->d_tm, f->nch, f->d_cm, f->block, f->nch, frames, f->s));
+    HIP_TRY(hipMemcpyAsync(f->h_out[slot], f->d_tm, bytes, hipMemcpyDeviceToHost, f->s));
+    HIP_TRY(hipEventRecord(f->done[slot], f->s));
+    f->queue.push_back({slot, frames, 0});
+    f->fill = 0;
+    f->fill_slot ^= 1;
+    return RTFB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int RTFilterBankFeed_create(RTFilterBankFeed **feed, RTFilterBank *bank, size_t block_frames)
+{
+    if (!feed || !bank || !block_frames) return fail(RTFB_EINVAL, "RTFilterBankFeed_create: NULL or empty argument");
+    *feed = nullptr;
+    if (block_frames > ((size_t)1 << 24) || bank->nch * block_frames > ((size_t)1 << 28))
+        return fail(RTFB_ESIZE, "RTFilterBankFeed_create: channels x block_frames above 2^28 doubles");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    RTFilterBankFeed *f = new RTFilterBankFeed;
+    f->bank = bank;
+    f->nch = bank->nch;
+    f->block = block_frames;
+    const size_t bytes = f->nch * f->block * sizeof(double);
+    int rc = RTFB_OK;
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail_hip(e, what);
+        return e == hipSuccess;
+    };
+    hipok(hipStreamCreateWithFlags(&f->s, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 2 && !rc; ++k)
+        hipok(hipHostMalloc(reinterpret_cast<void **>(&f->h_in[k]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
+            hipok(hipHostMalloc(reinterpret_cast<void **>(&f->h_out[k]), bytes, hipHostMallocDefault), "hipHostMalloc") &&
+            hipok(hipEventCreateWithFlags(&f->done[k], hipEventDisableTiming), "hipEventCreate");
+    void *p = nullptr;
+    if (!rc && !(rc = pool_alloc(&p, bytes, bank->device))) f->d_tm = static_cast<double *>(p);
+    if (!rc && !(rc = pool_alloc(&p, bytes, bank->device))) f->d_cm = static_cast<double *>(p);
+    if (rc) {
+        const std::string keep = t_last_error;
+        feed_release(f);
+        delete f;
+        t_last_error = keep;
+        return rc;
+    }
+    *feed = f;
+    return RTFB_OK;
+}
+
+void RTFilterBankFeed_destroy(RTFilterBankFeed *feed)
+{
+    if (!feed) return;
+    feed_release(feed);
+    delete feed;
+}
+
+int RTFilterBankFeed_push(RTFilterBankFeed *f, const double *frames, size_t nframes, size_t *accepted)
+{
+    if (accepted) *accepted = 0;
+    if (!f || (!frames && nframes)) return fail(RTFB_EINVAL, "RTFilterBankFeed_push: NULL argument");
+    DeviceScope ds(f->bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    while (nframes) {
+        if (f->fill == 0 && f->queue.size() == 2) {          /* both output buffers hold unpopped frames */
+            if (accepted) return RTFB_OK;                    /* the caller sees how far it got and pops */
+            return fail(RTFB_ESIZE, "RTFilterBankFeed_push: two blocks are waiting to be popped; pop first");
+        }
+        const size_t take = std::min(nframes, f->block - f->fill);
+        std::memcpy(f->h_in[f->fill_slot] + f->fill * f->nch, frames, take * f->nch * sizeof(double));
+        f->fill += take;
+        frames += take * f->nch;
+        nframes -= take;
+        if (accepted) *accepted += take;
+        if (f->fill == f->block) {
+            int rc = feed_submit(f);
+            if (rc) return rc;
+        }
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBankFeed_flush(RTFilterBankFeed *f)
+{
+    if (!f) return fail(RTFB_EINVAL, "NULL feed");
+    DeviceScope ds(f->bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    if (f->fill && f->queue.size() == 2)
+        return fail(RTFB_ESIZE, "RTFilterBankFeed_flush: two blocks are waiting to be popped; pop first");
+    int rc = feed_submit(f);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(f->s));
+    return RTFB_OK;
+}
+
+/* Blocks until the oldest submitted block has come back (nothing to wait for: returns at once). */
+int RTFilterBankFeed_wait(RTFilterBankFeed *f)
+{
+    if (!f) return fail(RTFB_EINVAL, "NULL feed");
+    if (f->queue.empty()) return RTFB_OK;
+    HIP_TRY(hipEventSynchronize(f->done[f->queue.front().slot]));
+    return RTFB_OK;
+}
+
+/* Submitted blocks that have not been popped completely (0..2). */
+size_t RTFilterBankFeed_pending(RTFilterBankFeed *f) { return f ? f->queue.size() : 0; }
+
+size_t RTFilterBankFeed_available(RTFilterBankFeed *f)
+{
+    if (!f) return 0;
+    size_t n = 0;
+    for (const RTFilterBankFeed::InFlight &b : f->queue) {
+        if (hipEventQuery(f->done[b.slot]) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        n += b.frames - b.popped;
+    }
+    return n;
+}
+
+int RTFilterBankFeed_pop(RTFilterBankFeed *f, double *frames, size_t max_frames, size_t *got)
+{
+    if (!f || !got || (!frames && max_frames)) return fail(RTFB_EINVAL, "RTFilterBankFeed_pop: NULL argument");
+    *got = 0;
+    while (max_frames && !f->queue.empty()) {
+        RTFilterBankFeed::InFlight &b = f->queue.front();
+        if (hipEventQuery(f->done[b.slot]) != hipSuccess) {
+            (void)hipGetLastError();
+            break;                               /* not there yet: non-blocking */
+        }
+        const size_t take = std::min(max_frames, b.frames - b.popped);
+        std::memcpy(frames, f->h_out[b.slot] + b.popped * f->nch, take * f->nch * sizeof(double));
+        frames += take * f->nch;
+        b.popped += take;
+        *got += take;
+        max_frames -= take;
+        if (b.popped == b.frames) f->queue.pop_front();
+    }
+    return RTFB_OK;
 }
 
 }  /* extern "C" */

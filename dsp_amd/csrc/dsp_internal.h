@@ -98,6 +98,8 @@ hipError_t launch_state_unpack(const double *pack, double *state, double *fval, 
                                hipStream_t s);
 hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0, const double *v, size_t v_ld,
                                  const double *M, int N, int count, int write_all, hipStream_t s);
+hipError_t launch_transpose(double *dst, size_t ld_dst, const double *src, size_t ld_src, size_t rows, size_t cols,
+                            hipStream_t s);
 bool iir_scan_supported(int order);
 
 }  // namespace dsp

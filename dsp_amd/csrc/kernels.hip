@@ -833,6 +833,26 @@ compose_states_kernel(double *dst, size_t dst_ld, const double *src0, const doub
     if (!write_all && i <= N) dst[i] = sbuf[cur][i];
 }
 
+/* dst[c * ld_dst + r] = src[r * ld_src + c], r < rows, c < cols: 32 x 32 tiles through LDS (padded), coalesced on
+ * both sides.  Turns time-major frames (one sample per channel) into the channel-major rows the filters read, and
+ * back (RTFilterBankFeed). */
+__global__ void __launch_bounds__(256)
+transpose_kernel(double *dst, size_t ld_dst, const double *src, size_t ld_src, size_t rows, size_t cols)
+{
+    __shared__ double tile[32][33];
+    const size_t r0 = (size_t)blockIdx.y * 32, c0 = (size_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       /* 32 x 8 threads */
+    for (int j = ty; j < 32; j += 8) {
+        const size_t r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[j][tx] = src[r * ld_src + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const size_t c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) dst[c * ld_dst + r] = tile[tx][j];
+    }
+}
+
 /* Synthetic input generator; two samples per thread. */
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 {
@@ -1002,6 +1022,16 @@ hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0,
     if (N < 1 || N > 16 || count < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(compose_states_kernel, dim3(1), dim3(kWave), 0, s, dst, dst_ld, src0, v, v_ld, M, N, count,
                        write_all);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose(double *dst, size_t ld_dst, const double *src, size_t ld_src, size_t rows, size_t cols,
+                            hipStream_t s)
+{
+    if (!rows || !cols) return hipSuccess;
+    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, dst, ld_dst, src, ld_src, rows, cols);
     return hipGetLastError();
 }
 

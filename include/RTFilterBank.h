@@ -137,6 +137,37 @@ EXPORT int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t 
                                         const double *in, size_t ld_in, size_t n, void *hip_stream);
 EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
 
+/* The same loop for HOST arrays -- what an unchanged caller of the reference holds: in/out are ordinary
+ * (pageable) host memory, channel-major, ld_* in doubles, in == out allowed.  The block is moved through the GPU in
+ * chunks of time (all channels x nt samples each, so the carried state streams from chunk to chunk): the CPU
+ * stages each chunk into a ring of two pinned buffers while the GPU works on the previous one, H2D / filter / D2H
+ * run on three streams, and the results leave through a second pinned ring.  Bounded by the host link and the
+ * host's memcpy rate (PCIe: 16 B/sample), never by the kernels; blocks until out[] is complete.  The rings
+ * (4 x 64 MiB pinned, 4 x 64 MiB on the device) are created by the first call.  (ref: src/RTFilter.c:111-119.) */
+EXPORT int RTFilterBank_updaten_host(RTFilterBank *bank, double *out, size_t ld_out,
+                                     const double *in, size_t ld_in, size_t n);
+
+/* ---- per-sample producers ------------------------------------------------------------------
+ * The reference's real-time entry is RTFilter_update(filter, sample): one call per filter and sample
+ * (src/RTFilter.c:98-108; python/dsp.py:6-13,35-38 wraps it in an iterator).  A GPU cannot serve that call by
+ * call; RTFilterBankFeed coalesces it: the producer pushes FRAMES (frame t = one sample for every channel of the
+ * bank, nch doubles, time-major), the feed collects `block_frames` of them in pinned memory, sends the block
+ * through the device (H2D, frames -> channel rows, RTFilterBank_updaten with the carried state, rows -> frames,
+ * D2H) and the consumer pops filtered frames in the same order.  Outputs equal RTFilter_update applied per
+ * channel and frame; latency is one block.  Two blocks may be in flight: when a third would be needed
+ * before the oldest was popped, _push stops there and reports the frames it took in *accepted (RTFB_OK; with
+ * accepted == NULL that situation is RTFB_ESIZE).  _pop never blocks (returns what is ready), _wait blocks until the
+ * oldest submitted block is back; _flush submits a partial block and waits for everything in flight.  One producer/consumer thread per feed. */
+typedef struct RTFilterBankFeed RTFilterBankFeed;
+EXPORT int    RTFilterBankFeed_create(RTFilterBankFeed **feed, RTFilterBank *bank, size_t block_frames);
+EXPORT void   RTFilterBankFeed_destroy(RTFilterBankFeed *feed);
+EXPORT int    RTFilterBankFeed_push(RTFilterBankFeed *feed, const double *frames, size_t nframes, size_t *accepted);
+EXPORT int    RTFilterBankFeed_pop(RTFilterBankFeed *feed, double *frames, size_t max_frames, size_t *got);
+EXPORT size_t RTFilterBankFeed_available(RTFilterBankFeed *feed);    /* filtered frames ready to pop */
+EXPORT size_t RTFilterBankFeed_pending(RTFilterBankFeed *feed);      /* submitted blocks not yet fully popped: 0..2 */
+EXPORT int    RTFilterBankFeed_wait(RTFilterBankFeed *feed);      /* until the oldest submitted block is back */
+EXPORT int    RTFilterBankFeed_flush(RTFilterBankFeed *feed);
+
 /* RTFilter_reset on every channel (state untouched, src/RTFilter.c:55-58). */
 EXPORT int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream);
 
