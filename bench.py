@@ -145,6 +145,10 @@ def main():
                     help="config 2: how the resident 2^20-sample streams lie in HBM: `rows` = one row of 2^20 samples per "
                          "channel, `blocks` = 16 block buffers of 1024 x 64K")
     ap.add_argument("--block-pad", type=int, default=0, help="layout blocks: extra doubles per row")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed: keep the GPU busy with the hot path for this long BEFORE the warm-up steps, so "
+                         "that the shader/memory clocks have left their idle state (a step takes ~4 %% longer "
+                         "during the first ~25 ms after an idle period: tools/rampup.py); 0 disables")
     ap.add_argument("--no-extra", action="store_true",
                     help="default run only: skip the compact config-3 and config-5 legs attached under `other_configs`")
     args = ap.parse_args()
@@ -212,6 +216,17 @@ def main():
             ev[1].record(stream)
         step_no[0] += 1
 
+    # untimed, before the warm-up: bring the device out of its idle clocks (profiles/r2_rampup.txt)
+    settle_steps = 0
+    t_settle = time.perf_counter()
+    while args.settle_ms > 0 and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(32):
+            step()
+        settle_steps += 32
+        torch.cuda.synchronize()
+    if settle_steps:
+        step_no[0] = 0
+        bank.reset(stream)
     for _ in range(args.warmup):
         step()
     # ONE pair of HIP events brackets the timed steps on the launch stream: average launch duration =
@@ -278,7 +293,8 @@ def main():
                                    "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
-                       "layout": args.layout, "row_pitch_doubles": pitch,
+                       "layout": args.layout, "row_pitch_doubles": pitch, "settle_steps_untimed": settle_steps,
+                       "buffers": "x @ %#x, y @ %#x" % (xbuf.data_ptr(), ybuf.data_ptr()),
                        "distinct_designs": CHANNELS if args.jitter else 1,
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -617,6 +633,11 @@ def main_stream16(args, emit=True):
         if ev is not None:
             ev[1].record(stream)
 
+    # untimed, before the warm-up: bring the device out of its idle clocks (same count on every rank: the
+    # multi-GPU step holds a collective)
+    settle_steps = min(128, int(round(args.settle_ms / 3.7 * world))) if args.settle_ms > 0 else 0
+    for _ in range(settle_steps):
+        step()
     for _ in range(args.warmup):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -650,6 +671,7 @@ def main_stream16(args, emit=True):
                                    "chunked state-space scan split in time, state hand-off between chunks"
                                    % args.stream_log2,
                        "samples_per_gpu": n, "sub_chunks": fs.last_split, "decay_length": fs.decay_length,
+                       "settle_steps_untimed": settle_steps,
                        "parallelism": "time-split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -70,7 +70,12 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile0 = smem;
     char *tile1 = smem + kPTile;
-    double *pbuf = reinterpret_cast<double *>(smem + 2 * kPTile);    /* 64 x N start states */
+    /* 64 x N start states, one slot per row.  The slot pitch in 16-byte units must be odd: lanes write and
+     * read their slots with b128 accesses, 16 lanes per LDS cycle, and at a pitch of N = 8 doubles (4 units)
+     * lanes l and l+4 meet in the same banks -- the 4.7e6 SQ_LDS_BANK_CONFLICT cycles per launch of round 1,
+     * all of them from these two accesses (the swizzled sample tiles are conflict-free). */
+    constexpr int kPPitch = (N % 2 == 0 && (N / 2) % 2 == 0) ? N + 2 : N;
+    double *pbuf = reinterpret_cast<double *>(smem + 2 * kPTile);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,7 +88,11 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     if (nlev > kPLevels) nlev = kPLevels;
 
     /* diagnostics (DSP_AMD_SCAN_STAMPS=1 allocates g.aux): 100 MHz timestamps of one workgroup's milestones */
+#ifdef DSP_PIPE_STAMPS
     unsigned long long *dbg = g.aux ? reinterpret_cast<unsigned long long *>(g.aux) + (size_t)gi * 32 : nullptr;
+#else
+    constexpr unsigned long long *dbg = nullptr;       /* tools/variant.sh -DDSP_PIPE_STAMPS builds the stamped twin */
+#endif
     if (dbg && lane == 0 && front) {
         dbg[0] = __builtin_amdgcn_s_memrealtime();
         dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        /* HW_ID: simd, cu, sh, se */
@@ -105,21 +114,49 @@ iir_pipe_kernel(GroupView g, BlockIO io)
      * then run under the cold-start HBM latency instead of in front of it. */
     d2 pre0[kPPieces], pre1[kPPieces];
 
+    /* kWhole launches issue the prefetch as opaque instructions and count vmcnt by hand (park_wait below).
+     * hipcc's waitcnt insertion is path-insensitive: because a fetch may issue nothing (past the end) it assumed
+     * at every tile write that the youngest 16 loads in flight were the ones needed and drained BOTH prefetched
+     * segments -- an effective prefetch distance of one -- and it made the front wait for loads of the back
+     * wave's branch that follow it in the linearised flow graph.  By hand the distance is really two: while
+     * segment i is parked, the loads of segment i+1 stay in flight.  The front wave issues no other vector-memory
+     * instruction, so the counter holds these loads only (the stamped diagnostic build adds stores and therefore
+     * waits for everything). */
+#ifdef DSP_PIPE_STAMPS
+    constexpr int kNewerInFlight = 0;
+#else
+    constexpr int kNewerInFlight = kPPieces;
+#endif
     auto fetch = [&](int seg, d2(&pre)[kPPieces]) {
         const size_t base = (size_t)seg * kPSeg;
         if (base >= n) return;
         const size_t left = n - base;
         const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
-        /* Because a fetch may issue nothing (past the end), hipcc's waitcnt pass assumes at every tile write
-         * that the youngest 16 loads in flight are the ones it needs, i.e. it waits for BOTH prefetched
-         * segments: an effective prefetch distance of one segment.  Measured, that is the better setting:
-         * with the full distance of two (unconditional fetches) the workgroups that the CU favours run
-         * further ahead, the spread of finish times grows from 180-231 to 148-240 us and a 64K block takes
-         * 0.246 instead of 0.240 ms. */
         if constexpr (kWhole) {
-#pragma unroll
-            for (int i = 0; i < kPPieces; ++i)
-                pre[i] = stream_load(reinterpret_cast<const d2 *>(src + base + 2 * (i * kWave + lane)));
+            static_assert(kPPieces == 16, "four base pointers x four 1 KiB offsets");
+            const double *p0 = src + base + 2 * lane;          /* piece i of the lane: + i * 1024 bytes */
+            const double *p1 = p0 + 4 * 2 * kWave, *p2 = p0 + 8 * 2 * kWave, *p3 = p0 + 12 * 2 * kWave;
+            asm volatile(
+                "global_load_dwordx4 %0, %16, off nt\n\t"
+                "global_load_dwordx4 %1, %16, off offset:1024 nt\n\t"
+                "global_load_dwordx4 %2, %16, off offset:2048 nt\n\t"
+                "global_load_dwordx4 %3, %16, off offset:3072 nt\n\t"
+                "global_load_dwordx4 %4, %17, off nt\n\t"
+                "global_load_dwordx4 %5, %17, off offset:1024 nt\n\t"
+                "global_load_dwordx4 %6, %17, off offset:2048 nt\n\t"
+                "global_load_dwordx4 %7, %17, off offset:3072 nt\n\t"
+                "global_load_dwordx4 %8, %18, off nt\n\t"
+                "global_load_dwordx4 %9, %18, off offset:1024 nt\n\t"
+                "global_load_dwordx4 %10, %18, off offset:2048 nt\n\t"
+                "global_load_dwordx4 %11, %18, off offset:3072 nt\n\t"
+                "global_load_dwordx4 %12, %19, off nt\n\t"
+                "global_load_dwordx4 %13, %19, off offset:1024 nt\n\t"
+                "global_load_dwordx4 %14, %19, off offset:2048 nt\n\t"
+                "global_load_dwordx4 %15, %19, off offset:3072 nt"
+                : "=&v"(pre[0]), "=&v"(pre[1]), "=&v"(pre[2]), "=&v"(pre[3]), "=&v"(pre[4]), "=&v"(pre[5]),
+                  "=&v"(pre[6]), "=&v"(pre[7]), "=&v"(pre[8]), "=&v"(pre[9]), "=&v"(pre[10]), "=&v"(pre[11]),
+                  "=&v"(pre[12]), "=&v"(pre[13]), "=&v"(pre[14]), "=&v"(pre[15])
+                : "v"(p0), "v"(p1), "v"(p2), "v"(p3));
         } else if (seg_len == kPSeg && io.aligned16) {
 #pragma unroll
             for (int i = 0; i < kPPieces; ++i)
@@ -132,6 +169,23 @@ iir_pipe_kernel(GroupView g, BlockIO io)
                 if (e < seg_len) v.x = src[base + e];
                 if (e + 1 < seg_len) v.y = src[base + e + 1];
                 pre[i] = v;
+            }
+        }
+    };
+    /* kWhole: piece i of a prefetched segment has arrived once at most (newer + 15 - i) loads are outstanding,
+     * `newer` = loads issued after that segment's.  The wait clobbers "memory", so the tile write that follows
+     * it (a memory operation) cannot be scheduled above it; the loaded registers themselves must not be read
+     * in between -- nothing does, and the listing is the check (no copy of them before the wait). */
+    auto park_wait = [&](int i, bool newer_in_flight) {
+        if constexpr (kWhole) {
+            const int cnt = (newer_in_flight ? kNewerInFlight : 0) + kPPieces - 1 - i;
+            switch (cnt) {
+#define DSP_PW(C) case C: asm volatile("s_waitcnt vmcnt(" #C ")" ::: "memory"); break;
+                DSP_PW(0) DSP_PW(1) DSP_PW(2) DSP_PW(3) DSP_PW(4) DSP_PW(5) DSP_PW(6) DSP_PW(7)
+                DSP_PW(8) DSP_PW(9) DSP_PW(10) DSP_PW(11) DSP_PW(12) DSP_PW(13) DSP_PW(14) DSP_PW(15)
+                DSP_PW(16) DSP_PW(17) DSP_PW(18) DSP_PW(19) DSP_PW(20) DSP_PW(21) DSP_PW(22) DSP_PW(23)
+                DSP_PW(24) DSP_PW(25) DSP_PW(26) DSP_PW(27) DSP_PW(28) DSP_PW(29) DSP_PW(30) DSP_PW(31)
+#undef DSP_PW
             }
         }
     };
@@ -189,16 +243,28 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             rotate_priority(prio_slot + it);
             if (it == 0) stamp(1);                            /* set-up done */
             if (it == 8) stamp(11);
+            if (it == 9) stamp(22);
             lds_barrier();                                    /* barrier 0 */
             if (it < nseg) {
+                if (it + 1 < nseg) {                          /* segment it+1's loads are younger, still flying */
 #pragma unroll
-                for (int i = 0; i < kPPieces; ++i)
-                    *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
+                    for (int i = 0; i < kPPieces; ++i) {
+                        park_wait(i, true);
+                        *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kPPieces; ++i) {
+                        park_wait(i, false);
+                        *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
+                    }
+                }
             }
             lds_barrier();                                    /* barrier 1 */
             if (it >= nseg) return;
             if (it == 0) stamp(7);
             if (it == 8) stamp(12);
+            if (it == 9) stamp(23);
             fetch(it + 2, pre);
 
             const bool seeded = seed_stream && it == 0;
@@ -208,52 +274,50 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = 0.0;
             v[N] = tailv;
-#ifdef EXP_ZS_RECUR
-            /* zero-state pass by the recurrence itself: 2N+1 FMAs per sample with the coefficients in SGPRs (one
-             * scalar batch per segment) instead of N FMAs per sample against 16 table batches, each an exposed
-             * trip to the scalar cache */
             {
-                double zb[N + 1], za[N + 1];
-                load_coefs(zb, za);
-                constexpr int kBurst = PT / 4;
-#pragma unroll
-                for (int h = 0; h < PT / 2; h += kBurst) {
-                    d2 xq[kBurst];
-#pragma unroll
-                    for (int q = 0; q < kBurst; ++q)
-                        xq[q] = *reinterpret_cast<const d2 *>(row + (((h + q) << 4) ^ rx));
-#pragma unroll
-                    for (int q = 0; q < kBurst; ++q) {
-                        (void)iir_step_fused<N, kUnitA0>(xq[q].x, v, zb, za);
-                        (void)iir_step_fused<N, kUnitA0>(xq[q].y, v, zb, za);
-                    }
-                }
-            }
-            if (false) {
-#else
-            {
-#endif
             /* the row comes out of LDS in one burst; the table arrives in scalar batches of kZB samples
              * (<= 32 SGPRs each), so a batch's wait is not also a wait for LDS */
             d2 xr[PT / 2];
 #pragma unroll
             for (int q = 0; q < PT / 2; ++q) xr[q] = *reinterpret_cast<const d2 *>(row + ((q << 4) ^ rx));
+            /* Scalar loads return out of order, so a wait is always a wait for ALL of them: a batch requested
+             * after the wait for the one in use is the only kind that overlaps arithmetic.  Two register sets
+             * take turns -- the first FMA of a batch carries the wait, then the next batch is requested, then
+             * the remaining FMAs of the current one issue while it travels (~100 cycles from the scalar cache,
+             * tools/sload_latency.hip, against 64 cycles of FMAs per batch). */
             constexpr int kZB = N <= 4 ? 4 : 2;
-#pragma unroll
-            for (int k0 = 0; k0 < PT; k0 += kZB) {
-                double gk[kZB][N];
+            static_assert(PT % (2 * kZB) == 0, "batches come in pairs");
+            double ga[kZB][N], gb[kZB][N];
+            auto zs_load = [&](double(&gk)[kZB][N], int k0) {
 #pragma unroll
                 for (int k = 0; k < kZB; ++k) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) gk[k][i] = gtab[(k0 + k) * N + i];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto zs_mac = [&](const double(&gk)[kZB][N], int k0, int from, int to) {
 #pragma unroll
-                for (int k = 0; k < kZB; ++k) {
+                for (int f = from; f < to; ++f) {
+                    const int k = f / N, i = f % N;
                     const double xk = ((k0 + k) & 1) ? xr[(k0 + k) >> 1].y : xr[(k0 + k) >> 1].x;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) v[i] = __builtin_fma(gk[k][i], xk, v[i]);
+                    v[i] = __builtin_fma(gk[k][i], xk, v[i]);
                 }
+            };
+            zs_load(ga, 0);
+#pragma unroll
+            for (int k0 = 0; k0 < PT; k0 += 2 * kZB) {
+                __builtin_amdgcn_sched_barrier(0);
+                zs_mac(ga, k0, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                zs_load(gb, k0 + kZB);
+                __builtin_amdgcn_sched_barrier(0);
+                zs_mac(ga, k0, 1, kZB * N);
+                __builtin_amdgcn_sched_barrier(0);
+                zs_mac(gb, k0 + kZB, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k0 + 2 * kZB < PT) zs_load(ga, k0 + 2 * kZB);
+                __builtin_amdgcn_sched_barrier(0);
+                zs_mac(gb, k0 + kZB, 1, kZB * N);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (tailv != 0.0) {
@@ -280,6 +344,22 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             /* Kogge-Stone over the 64 rows, zero carry-in.  The level's matrix A^(32 d) is wave-uniform: it
              * comes through the scalar cache in batches of kKR rows (<= 64 SGPRs), not through LDS, whose
              * pipe the two roles' tile traffic already keeps busy. */
+            /* Row batches of the level matrices take turns in two register sets like the table above; the first
+             * batch of the next level travels under the last FMAs of this one (the table holds kScan2Levels >
+             * kPLevels matrices, so the request past the last level stays inside it). */
+            constexpr int kKR = N <= 4 ? N : 2;
+            constexpr int kKB = (N + kKR - 1) / kKR;
+            static_assert(kScan2Levels > kPLevels, "the look-ahead load of level lvl + 1 needs a matrix there");
+            double mbuf[2][kKR][N];
+            auto px_load = [&](double(&m)[kKR][N], int lvl, int bi) {
+#pragma unroll
+                for (int r = 0; r < kKR; ++r) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        m[r][j] = (bi * kKR + r < N) ? ptab[(lvl * N + (bi * kKR + r < N ? bi * kKR + r : 0)) * N + j] : 0.0;
+                }
+            };
+            px_load(mbuf[0], 0, 0);
             for (int lvl = 0; lvl < nlev; ++lvl) {
                 const int d = 1 << lvl;
                 double u[N];
@@ -288,28 +368,33 @@ iir_pipe_kernel(GroupView g, BlockIO io)
                     const double t = __shfl_up(v[i], d, kWave);
                     u[i] = lane >= d ? t : 0.0;
                 }
-                constexpr int kKR = N <= 4 ? N : 4;
 #pragma unroll
-                for (int r0 = 0; r0 < N; r0 += kKR) {
-                    double m[kKR][N];
+                for (int bi = 0; bi < kKB; ++bi) {
+                    double(&cur)[kKR][N] = mbuf[bi & 1];
+                    double(&nxt)[kKR][N] = mbuf[(bi + 1) & 1];
+                    auto px_mac = [&](int from, int to) {
 #pragma unroll
-                    for (int r = 0; r < kKR; ++r) {
+                        for (int j = from; j < to; ++j) {
 #pragma unroll
-                        for (int j = 0; j < N; ++j) m[r][j] = (r0 + r < N) ? ptab[(lvl * N + r0 + r) * N + j] : 0.0;
-                    }
+                            for (int r = 0; r < kKR; ++r)
+                                if (bi * kKR + r < N)
+                                    v[bi * kKR + r] = __builtin_fma(cur[r][j], u[j], v[bi * kKR + r]);
+                        }
+                    };
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-#pragma unroll
-                        for (int r = 0; r < kKR; ++r)
-                            if (r0 + r < N) v[r0 + r] = __builtin_fma(m[r][j], u[j], v[r0 + r]);
-                    }
+                    px_mac(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (bi + 1 < kKB) px_load(nxt, lvl, bi + 1);
+                    else if (kKB % 2 == 0) px_load(nxt, lvl + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    px_mac(1, N);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (kKB % 2 == 1) px_load(mbuf[0], lvl + 1, 0);
             }
             /* publish: row j+1 starts (with zero carry-in) from the state row j ends in */
             if (lane < kPRows - 1) {
-                double *slot = pbuf + (lane + 1) * N;
+                double *slot = pbuf + (lane + 1) * kPPitch;
 #pragma unroll
                 for (int i = 0; i < N; ++i) slot[i] = v[i];
             }
@@ -348,20 +433,37 @@ iir_pipe_kernel(GroupView g, BlockIO io)
          * tables loaded above, so that the front is not held at its first barrier until they have arrived */
         lds_barrier();
         lds_barrier();
+        /* The propagator's loads must be retired HERE, on every path out of this branch: hipcc's waitcnt pass
+         * works on the linearised flow graph, in which the front wave's code follows this branch, and a load it
+         * believes pending on registers the front reuses (the loop below may run zero times, as far as it knows)
+         * costs the front a vmcnt(0) -- a full trip to HBM for the prefetch it has just issued, every segment. */
+#pragma unroll
+        for (int e = 0; e < N * N; e += 8) {
+            if constexpr (N * N - 0 >= 8) {
+                if (e + 8 <= N * N)
+                    asm volatile("" ::"v"(tp[e]), "v"(tp[e + 1]), "v"(tp[e + 2]), "v"(tp[e + 3]), "v"(tp[e + 4]),
+                                 "v"(tp[e + 5]), "v"(tp[e + 6]), "v"(tp[e + 7]));
+            }
+        }
+#pragma unroll
+        for (int e = (N * N) / 8 * 8; e < N * N; ++e) asm volatile("" ::"v"(tp[e]));
+        asm volatile("" ::"v"(ylast));
         for (int it = 1; it <= nseg; ++it) {
             const int seg = it - 1;
             char *tile = (seg & 1) ? tile1 : tile0;
             rotate_priority(prio_slot + it);
+            if (seg == 9) stamp(19);
             lds_barrier();                                    /* barrier 0 */
             double s[N + 1];
             {
-                const double *slot = pbuf + lane * N;
+                const double *slot = pbuf + lane * kPPitch;
 #pragma unroll
                 for (int i = 0; i < N; ++i) s[i] = slot[i];
             }
             lds_barrier();                                    /* barrier 1 */
             if (seg == 0) stamp(3);                           /* back starts segment 0 */
             if (seg == 8) stamp(15);
+            if (seg == 9) stamp(21);
 
             const size_t base = (size_t)seg * kPSeg;
             const size_t left = n - base;
@@ -424,6 +526,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 
             /* store the segment, coalesced (this wave wrote the whole tile: in-order LDS) */
             if (seg == 0) stamp(10);
+            if (seg == 8) stamp(18);
             wave_sync();
             if (kWhole || (seg_len == kPSeg && io.aligned16)) {
 #pragma unroll 8
@@ -455,7 +558,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 template <int N>
 static hipError_t launch_pipe_n(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
-    const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * N;
+    const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * (N + 2);
     const bool whole = io.aligned16 && io.n % kPSeg == 0;
     if (g.unit_a0 && whole)
         hipLaunchKernelGGL((iir_pipe_kernel<N, true, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);

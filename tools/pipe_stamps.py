@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: timeline of the pipelined IIR kernel's workgroups (DSP_AMD_SCAN_STAMPS=1 path).
+"""Diagnostic: timeline of the pipelined IIR kernel's workgroups.  Needs the stamped library build:
+  tools/variant.sh stamps -DDSP_PIPE_STAMPS && DSP_AMD_LIBRARY=$PWD/tools/_build/libdsp_stamps.so python tools/pipe_stamps.py
 
 Stamps are 100 MHz s_memrealtime: [0] entry, [1] set-up done (front), [2] segment 0 published,
 [3] back starts segment 0, [5] back done.  usage: pipe_stamps.py [channels] [n]"""
@@ -52,6 +53,13 @@ for n in [int(v) for v in sys.argv[2:]] or [2048, 16384, 65536]:
         q("  steady it=8 front: zero-state", st[:, 13] - st[:, 12])
         q("  steady it=8 front: prefix+publish", st[:, 14] - st[:, 13])
         q("  steady: back seg 8 start - front it=8 b1", st[:, 15] - st[:, 12])
+        q("  steady front: it=8 b1 -> it=9 top", st[:, 22] - st[:, 12])
+        q("  steady front: it=9 top -> it=9 b1 (wait+park)", st[:, 23] - st[:, 22])
+        q("  steady front period (b1 -> b1)", st[:, 23] - st[:, 12])
+        q("  steady back: seg 8 b1 -> recurrences done", st[:, 18] - st[:, 15])
+        q("  steady back: -> stores issued, next top", st[:, 19] - st[:, 18])
+        q("  steady back: next top -> seg 9 b1 (wait)", st[:, 21] - st[:, 19])
+        q("  steady back period (b1 -> b1)", st[:, 21] - st[:, 15])
     if n >= 10 * 2048:
         clk = (st[:, 17] - st[:, 16]) / (st[:, 14] - st[:, 0])   # (cycles/100) per us = 1e-2 cycles/us
         q("  shader clock GHz (entry -> it=8)", clk * 0.1)
