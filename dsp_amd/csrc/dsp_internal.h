@@ -26,7 +26,7 @@ constexpr int kFirT = 32;            /* FIR kernel: outputs per lane            
 constexpr int kFirR = 8;             /* FIR kernel: outputs accumulated together      */
 constexpr int kFirSeg = kWave * kFirT;   /* outputs per wavefront                    */
 constexpr int kMaxFirTaps = 4096;
-constexpr int kFirMfmaMinTaps = 17;  /* from here the FP64 matrix cores beat the bit-exact VALU kernel (tools/fir_sweep.py) */
+constexpr int kFirMfmaMinTaps = 2;   /* the persistent matrix-core kernel streams at ~4.9 TB/s from 2 taps up; the bit-exact VALU kernel falls from 4.6 (2 taps) to 4.1 (16): profiles/r2_fir_sweep.txt */
 
 /* One launch group: channels of the bank that share a kernel. All pointers are
  * device pointers; arrays are indexed by the group-local channel index g. */

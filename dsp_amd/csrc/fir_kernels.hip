@@ -415,10 +415,12 @@ constexpr int kMfmaPre2 = 10;   /* the same as 16-byte pairs when the rows allow
                                    seg_base and hist are multiples of 16) */
 constexpr int kMfmaPreElems = 2 * kMfmaPre2 * kMfmaWaves * kWave;   /* 5120 >= 19 * 256: LDS is sized for it */
 
-struct MfmaOperands {
+template <int NT>
+struct MfmaOperandsT {
     double a[4];
-    double b[4][kMfmaTiles];
+    double b[4][NT];
 };
+using MfmaOperands = MfmaOperandsT<kMfmaTiles>;
 /* Operand fetch with plain ds_read_b64 (two 32-lane groups, bank = dword mod 64: conflict-free at
  * pitch 18, 2 LDS cycles).  The four delta sub-steps use four base registers the compiler cannot
  * relate, otherwise it pairs neighbouring reads into ds_read2_b64, which is serviced in 16-lane
@@ -430,18 +432,22 @@ __device__ __forceinline__ lds_cdouble_p lds_opaque(const double *p)
     asm volatile("" : "+v"(off));
     return (lds_cdouble_p)(uintptr_t)off;
 }
-/* Sub-step u of outer step o: its tap column and the four input columns. */
-__device__ __forceinline__ void mfma_fetch(MfmaOperands &r, const lds_cdouble_p (&pa)[4],
+/* Sub-step u of outer step o: its tap column and the input columns of the wavefront's NT tiles, which lie
+ * `tile_stride` tiles apart (1: consecutive tiles, the persistent kernel; 4: the short heads, where the
+ * four wavefronts take one tile each). */
+template <int NT, int kTileStride = 1>
+__device__ __forceinline__ void mfma_fetch(MfmaOperandsT<NT> &r, const lds_cdouble_p (&pa)[4],
                                            const lds_cdouble_p (&pb)[4], int u, int o)
 {
     r.a[u] = pa[u][16 * o];
 #pragma unroll
-    for (int t = 0; t < kMfmaTiles; ++t) r.b[u][t] = pb[u][kPitch * 16 * t - kPitch * o];
+    for (int t = 0; t < NT; ++t) r.b[u][t] = pb[u][kPitch * 16 * kTileStride * t - kPitch * o];
 }
-__device__ __forceinline__ void mfma_apply(d4 (&acc)[kMfmaTiles], const MfmaOperands &r, int u)
+template <int NT>
+__device__ __forceinline__ void mfma_apply(d4 (&acc)[NT], const MfmaOperandsT<NT> &r, int u)
 {
 #pragma unroll
-    for (int t = 0; t < kMfmaTiles; ++t)
+    for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(r.a[u], r.b[u][t], acc[t], 0, 0, 0);
 }
 }  // namespace
@@ -451,9 +457,11 @@ __device__ __forceinline__ void mfma_apply(d4 (&acc)[kMfmaTiles], const MfmaOper
  * ragged end of the block).  One workgroup per item, everything guarded.
  * `ramp_first`: first output this kernel writes for a channel that is inside a partial_init ramp
  * (the exact head kernel covers what is before it); every other channel is served from output t0. */
+template <int NT>       /* NT = 4: wavefront w owns tiles 4w..4w+3 of the item; NT = 1 (heads of <= 1024 outputs): tile w */
 __global__ void __launch_bounds__(kMfmaWaves * kWave)
-fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_lo, int steady_hi)
+fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_lo, int steady_hi, long long head_out)
 {
+    static_assert(NT == 1 || NT == kMfmaTiles, "one tile per wavefront, or the persistent kernel's four");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);
 
@@ -472,7 +480,10 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
     const long long n = (long long)io.n;
     const int seg = (int)blockIdx.x < steady_lo ? (int)blockIdx.x : (int)blockIdx.x - steady_lo + steady_hi;
     const long long seg_base = (long long)seg * kMfmaSeg;
-    if (seg_base + kMfmaSeg <= first) return;                      /* whole workgroup */
+    /* the item that holds head_out is shared with the persistent kernel, which writes its outputs from
+     * max(head_out, first) on (a multiple of 256: whole accumulator tiles); this kernel stops there */
+    const long long stop = (head_out > seg_base && head_out < seg_base + kMfmaSeg) ? head_out : seg_base + kMfmaSeg;
+    if (stop <= first) return;                                     /* whole workgroup */
     const double *x = io.in + (size_t)chan * io.ld_in;
     double *out = io.out + (size_t)chan * io.ld_out;
     const double *st = g.state + (size_t)gi * g.state_ld;
@@ -483,7 +494,8 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
     const int nb_pad = hist + 32;                           /* taps at index k + 16 */
     double *bp = lds;
     double *xs = lds + nb_pad;
-    const int total = hist + kMfmaSeg + 16;                 /* inputs seg_base-hist .. seg_base+4096+15 */
+    const int span = (int)(stop - seg_base);                /* outputs of this item: 4096, or up to head_out */
+    const int total = hist + span + 16;                     /* inputs seg_base-hist .. seg_base+span+15 */
 
     for (int e = tid; e < nb_pad; e += kMfmaWaves * kWave) {
         const int k = e - 16;
@@ -495,35 +507,46 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
     {
         constexpr int kThreads = kMfmaWaves * kWave;
         double xr[kMfmaPre];
+        if (span == kMfmaSeg) {
 #pragma unroll
-        for (int k = 0; k < kMfmaPre; ++k) {
-            long long idx = seg_base - hist + tid + kThreads * k;
-            idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
-            xr[k] = x[idx];
-        }
+            for (int k = 0; k < kMfmaPre; ++k) {
+                long long idx = seg_base - hist + tid + kThreads * k;
+                idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
+                xr[k] = x[idx];
+            }
 #pragma unroll
-        for (int k = 0; k < kMfmaPre; ++k) {                /* LDS holds kMfmaPreElems >= 19 * 256 inputs */
-            const long long idx = seg_base - hist + tid + kThreads * k;
-            xs[xpos(tid + kThreads * k)] = (idx >= t0 && idx < n) ? xr[k] : 0.0;
+            for (int k = 0; k < kMfmaPre; ++k) {            /* LDS holds kMfmaPreElems >= 19 * 256 inputs */
+                const long long idx = seg_base - hist + tid + kThreads * k;
+                xs[xpos(tid + kThreads * k)] = (idx >= t0 && idx < n) ? xr[k] : 0.0;
+            }
+        } else {                                            /* short head: only what its tiles read */
+            for (int e = tid; e < total; e += kThreads) {
+                long long idx = seg_base - hist + e;
+                const bool ok = idx >= t0 && idx < n;
+                idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
+                const double v = x[idx];
+                xs[xpos(e)] = ok ? v : 0.0;
+            }
         }
-        for (int e = tid + kThreads * kMfmaPre; e < total; e += kThreads) {     /* very long filters */
+        for (int e = tid + kThreads * kMfmaPre; span == kMfmaSeg && e < total; e += kThreads) {     /* very long filters */
             const long long idx = seg_base - hist + e;
             xs[xpos(e)] = (idx >= t0 && idx < n) ? x[idx] : 0.0;
         }
     }
     __syncthreads();
+    if (256 * NT * wave >= span) return;                    /* this wavefront's tiles all lie past the stop */
 
     const int j = lane & 15, q = lane >> 4;
-    d4 acc[kMfmaTiles];
+    d4 acc[NT];
     if (seg_base > K) {                                     /* steady state: s[K-1] under every output */
 #pragma unroll
-        for (int t = 0; t < kMfmaTiles; ++t) acc[t] = (d4){tail, tail, tail, tail};
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){tail, tail, tail, tail};
     } else {                                                /* outputs that still sit on the carried state */
 #pragma unroll
-        for (int t = 0; t < kMfmaTiles; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long mp = seg_base + 256 * (kMfmaTiles * wave + t) + 16 * j + 4 * q + r - t0;
+                const long long mp = seg_base + 256 * (NT * wave + t) + 16 * j + 4 * q + r - t0;
                 acc[t][r] = (mp >= 0 && mp <= K - 2) ? st[mp] : tail;
             }
     }
@@ -538,27 +561,28 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         pa[u] = lds_opaque(bp + (4 + pij - q) + 4 * u);
-        pb[u] = lds_opaque(xs + kPitch * (hist / 16 + 64 * wave + j) + q + 4 * (3 - u));
+        pb[u] = lds_opaque(xs + kPitch * (hist / 16 + 16 * NT * wave + j) + q + 4 * (3 - u));
     }
-    MfmaOperands r;
+    MfmaOperandsT<NT> r;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mfma_fetch(r, pa, pb, u, 0);
+    for (int u = 0; u < 4; ++u) mfma_fetch<NT>(r, pa, pb, u, 0);
     for (int o = 1; o < steps; ++o) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            mfma_apply(acc, r, u);
-            mfma_fetch(r, pa, pb, u, o);
+            mfma_apply<NT>(acc, r, u);
+            mfma_fetch<NT>(r, pa, pb, u, o);
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mfma_apply(acc, r, u);
+    for (int u = 0; u < 4; ++u) mfma_apply<NT>(acc, r, u);
 
     /* D[row = q + 4 r][col = j]  ->  output 256 t + 16 j + 4 q + r, straight from the registers */
-    const long long m0 = seg_base + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
+    const long long m0 = seg_base + 256 * NT * wave + 16 * j + 4 * q;
     const bool whole = first <= seg_base && seg_base + kMfmaSeg <= n && io.aligned16;
 #pragma unroll
-    for (int t = 0; t < kMfmaTiles; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const long long m = m0 + 256 * t;
+        if (seg_base + 256 * (NT * wave + t) >= stop) break;              /* tiles of the persistent kernel */
         if (whole) {
             *reinterpret_cast<d2 *>(out + m) = (d2){acc[t][0], acc[t][1]};
             *reinterpret_cast<d2 *>(out + m + 2) = (d2){acc[t][2], acc[t][3]};
@@ -579,10 +603,14 @@ struct MfmaItem {
     double tail;            /* s[K-1] */
     const double *b;
     int K, dsn, hist, steps;
+    int emin;               /* first staged element that exists (> 0 only in the item that holds the block's
+                               first samples: what lies before them only ever meets outputs that are skipped) */
+    long long first;        /* block-local index of the first output this kernel writes for the channel */
 };
 
 
-__device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg)
+__device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg,
+                                              long long head_out, long long ramp_first)
 {
     MfmaItem it;
     const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
@@ -597,15 +625,22 @@ __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO 
     it.emax = last < it.hist + kMfmaSeg + 15 ? (int)last : it.hist + kMfmaSeg + 15;
     it.out = io.out + (size_t)chan * io.ld_out + seg_base;
     it.tail = as_const(g.state + (size_t)gi * g.state_ld)[it.K - 1];   /* written by an earlier kernel */
+    it.emin = seg_base < it.hist ? (int)(it.hist - seg_base) : 0;
+    it.first = head_out;
+    if (ramp_first > head_out) {                    /* groups with partial_init channels: g.aux is this launch's */
+        const bool ramp = as_const(g.kind)[it.dsn] == RTFB_KIND_FIR_PARTIAL && g.aux[2 * gi + 1] < it.K;
+        if (ramp) it.first = ramp_first;            /* the exact head kernel wrote everything before it */
+    }
     return it;
 }
 
 /* D[row = q + 4 r][col = j]  ->  output 256 t + 16 j + 4 q + r, straight from the registers */
 template <bool kAligned16>
-__device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *o0)
+__device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *o0, int skip)
 {
 #pragma unroll
     for (int t = 0; t < kMfmaTiles; ++t) {
+        if (t < skip) continue;                     /* tiles before the channel's first steady output */
         if (kAligned16) {
             *reinterpret_cast<d2 *>(o0 + 256 * t) = (d2){acc[t][0], acc[t][1]};
             *reinterpret_cast<d2 *>(o0 + 256 * t + 2) = (d2){acc[t][2], acc[t][3]};
@@ -625,7 +660,7 @@ __device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *
  * are in flight together and nothing makes the compiler drain vmcnt inside the item loop. */
 template <bool kAligned16>
 __global__ void __launch_bounds__(kMfmaWaves * kWave, 3)      /* 3 waves per SIMD: <= 168 VGPRs */
-fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
+fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long head_out, long long ramp_first)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);
@@ -643,7 +678,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
     int gi = (int)(idx / nseg);
     int seg = (int)(idx - (long long)gi * nseg);
 
-    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg);
+    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg, head_out, ramp_first);
     /* emax is odd here (hist + 4096 - 1 when the block ends with the item, else hist + 4096 + 15), so a pair
      * clamped to emax >> 1 never reaches past it; clamped positions only ever meet zero taps */
     double xr[kMfmaPre];
@@ -652,16 +687,18 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
         if constexpr (kAligned16) {
 #pragma unroll
             for (int k = 0; k < kMfmaPre2; ++k)
-                xr2[k] = *reinterpret_cast<const d2 *>(it.x0 + 2 * min(tid + kThreads * k, it.emax >> 1));
+                xr2[k] = *reinterpret_cast<const d2 *>(it.x0 + 2 * max(min(tid + kThreads * k, it.emax >> 1), it.emin >> 1));
         } else {
 #pragma unroll
-            for (int k = 0; k < kMfmaPre; ++k) xr[k] = it.x0[min(tid + kThreads * k, it.emax)];
+            for (int k = 0; k < kMfmaPre; ++k) xr[k] = it.x0[max(min(tid + kThreads * k, it.emax), it.emin)];
         }
     };
     prefetch(cur);
     int staged_dsn = -1;
     d4 acc[kMfmaTiles];
     double *pending = nullptr;                                  /* where the previous item's results go */
+    int pending_skip = 0;                                       /* ... and how many of this wavefront's tiles do not */
+    long long seg_base = (long long)(steady_lo + seg) * kMfmaSeg;
 
     for (; idx < idx_end; ++idx) {
         double *bp = lds;                                       /* taps at index k + 16 */
@@ -680,7 +717,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
             for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
         }
         for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
-            xs[xpos(e)] = cur.x0[min(e, cur.emax)];
+            xs[xpos(e)] = cur.x0[max(min(e, cur.emax), cur.emin)];
         if (cur.dsn != staged_dsn) {
             for (int e = tid; e < nb_pad; e += kThreads) {
                 const int k = e - 16;
@@ -691,22 +728,29 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
         /* The previous item's results leave only now: issued before the prefetch they would sit
          * between it and the wait above, and the compiler, joining the loop entry (no stores) with
          * the back edge, would wait for them too. */
-        if (pending) mfma_store<kAligned16>(acc, pending);
+        if (pending) mfma_store<kAligned16>(acc, pending, pending_skip);
         lds_barrier();
 
         /* next item: its inputs travel while this one is contracted */
+        /* tiles of this item that lie before the channel's first steady output (whole tiles: head_out and
+         * ramp_first are multiples of 256) */
+        const long long lead = cur.first - seg_base - 256 * kMfmaTiles * wave;
+        const int cur_skip = lead <= 0 ? 0 : (lead >= 256 * kMfmaTiles ? kMfmaTiles : (int)(lead >> 8));
         MfmaItem nxt = cur;
         if (idx + 1 < idx_end) {
             if (++seg == nseg) {                                /* next channel: a chain of scalar loads */
                 seg = 0;
                 ++gi;
-                nxt = mfma_item(g, io, gi, steady_lo);
+                nxt = mfma_item(g, io, gi, steady_lo, head_out, ramp_first);
             } else {                                            /* next segment of the same channel */
                 nxt.x0 += kMfmaSeg;
                 nxt.out += kMfmaSeg;
-                const long long last = (long long)io.n - 1 - ((long long)(steady_lo + seg) * kMfmaSeg - cur.hist);
+                const long long nb = (long long)(steady_lo + seg) * kMfmaSeg;
+                const long long last = (long long)io.n - 1 - (nb - cur.hist);
                 nxt.emax = last < cur.hist + kMfmaSeg + 15 ? (int)last : cur.hist + kMfmaSeg + 15;
+                nxt.emin = nb < cur.hist ? (int)(cur.hist - nb) : 0;
             }
+            seg_base = (long long)(steady_lo + seg) * kMfmaSeg;
             prefetch(nxt);
         }
 
@@ -731,21 +775,22 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi)
          * step, which then have 12 MFMAs (768 cycles) to arrive */
         MfmaOperands r;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) mfma_fetch(r, pa, pb, u, 0);
+        for (int u = 0; u < 4; ++u) mfma_fetch<kMfmaTiles>(r, pa, pb, u, 0);
         for (int o = 1; o < cur.steps; ++o) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                mfma_apply(acc, r, u);
-                mfma_fetch(r, pa, pb, u, o);
+                mfma_apply<kMfmaTiles>(acc, r, u);
+                mfma_fetch<kMfmaTiles>(r, pa, pb, u, o);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) mfma_apply(acc, r, u);
+        for (int u = 0; u < 4; ++u) mfma_apply<kMfmaTiles>(acc, r, u);
 
         pending = cur.out + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
+        pending_skip = cur_skip;
         cur = nxt;
     }
-    mfma_store<kAligned16>(acc, pending);
+    mfma_store<kAligned16>(acc, pending, pending_skip);
 }
 
 /* workgroups of fir_mfma_kernel the device holds at once for a given LDS size */
@@ -991,14 +1036,32 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);       /* segments per channel */
         /* steady segments: first output has more than kmax samples behind it (and lies past any
          * ramp head: nhead*S <= steady_lo*kMfmaSeg), the whole segment is inside the block */
-        int steady_lo = g.kmax / kMfmaSeg + 1;
+        /* The persistent kernel takes over at output head_out of every channel: the first multiple of 256
+         * (whole accumulator tiles) with more than kmax samples behind it, so everything from there on is in
+         * steady state; inside a partial_init ramp it takes over at ramp_first.  The item that holds head_out
+         * belongs to both kernels: the edge kernel writes its outputs before head_out (a tile or two of
+         * the 16), the persistent one the rest -- round 1 sent the whole first item of every channel, a
+         * sixteenth of a 64K block, through the edge kernel at 3.4 TB/s. */
+        long long head_out = 256LL * ((g.kmax + 1 + 255) / 256);
+        int steady_lo = (int)(head_out / kMfmaSeg);                 /* the item that holds head_out */
         int steady_hi = (int)(io.n / kMfmaSeg);
-        if (steady_lo > nwg) steady_lo = nwg;
-        if (steady_hi < steady_lo) steady_hi = steady_lo;
-        const int nedge = steady_lo + (nwg - steady_hi);
+        if (steady_lo >= steady_hi) {                               /* short block: no item is whole */
+            steady_lo = steady_hi = steady_lo < nwg ? steady_lo : nwg;
+            if (steady_hi > (int)(io.n / kMfmaSeg)) steady_hi = steady_lo = (int)(io.n / kMfmaSeg);
+            head_out = 0;                                           /* nothing is shared */
+        }
+        const bool shared_head = head_out > (long long)steady_lo * kMfmaSeg;
+        const int edge_lo = steady_lo + (shared_head ? 1 : 0);      /* leading items the edge kernel visits */
+        const int nedge = edge_lo + (nwg - steady_hi);
+        const long long ramp_first = g.has_partial ? (long long)nhead * S : 0;
         if (nedge > 0) {
-            hipLaunchKernelGGL(fir_mfma_edge_kernel, dim3(nedge, g.count), dim3(kMfmaWaves * kWave), mfma_lds,
-                               s, g, io, (long long)nhead * S, steady_lo, steady_hi);
+            /* only short heads (no whole edge item in front of them, no ragged end behind): one tile per wavefront */
+            if (shared_head && nedge == 1 && head_out <= 256 * kMfmaWaves)
+                hipLaunchKernelGGL(fir_mfma_edge_kernel<1>, dim3(nedge, g.count), dim3(kMfmaWaves * kWave), mfma_lds,
+                                   s, g, io, (long long)nhead * S, edge_lo, steady_hi, head_out);
+            else
+                hipLaunchKernelGGL(fir_mfma_edge_kernel<kMfmaTiles>, dim3(nedge, g.count), dim3(kMfmaWaves * kWave),
+                                   mfma_lds, s, g, io, (long long)nhead * S, edge_lo, steady_hi, head_out);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (steady_hi > steady_lo) {
@@ -1007,10 +1070,10 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
             if (grid > items) grid = items;
             if (io.aligned16)
                 hipLaunchKernelGGL(fir_mfma_kernel<true>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi);
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first);
             else
                 hipLaunchKernelGGL(fir_mfma_kernel<false>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi);
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {

@@ -63,8 +63,10 @@ typedef struct RTFilterDesign {
  *             time-parallel scan kernels when their group has fewer than 131072 channels (orders above
  *             8: at any width once a call brings >= 4096 samples, else below 65536 channels) and the
  *             design passes the conditioning probe,
- *             else on the bit-exact sequential kernel; FIR channels of >= 17 taps on the
- *             Toeplitz-tile FP64 MFMA kernel (else bit-exact).
+ *             else on the bit-exact sequential kernel; FIR channels of >= 2 taps on the
+ *             Toeplitz-tile FP64 MFMA kernel (4.9 TB/s at any short length, where the bit-exact kernel
+ *             falls from 4.7 at 2 taps to 3.5 at 32); short blocks on wide banks (>= 16384 channels,
+ *             <= 4096 samples, <= 32 taps) stay on the bit-exact lane-per-channel kernel in every mode.
  * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
  * SCAN        like AUTO but IIR channels always on the scan kernel (no probe, caller's choice). */
 #define RTFB_MODE_AUTO        0

@@ -215,7 +215,7 @@ def test_fir_short_blocks_on_a_wide_bank_lane_per_channel(G, mode_name, layout):
     x = G.make_inputs(92, nch, 5000)
     yg = gb(G.to_dev(x)).cpu().numpy()
     yo = ob.updaten(x, threads=8)
-    if mode_name == "sequential" or layout == "mixed<=16":
+    if mode_name == "sequential":                 # AUTO: the matrix-core kernel from 2 taps up (1e-12 bar)
         assert util.bits_equal(yg, yo)
     else:
         assert np.all(util.rel_to_peak(yg, yo) <= TOL_MFMA)

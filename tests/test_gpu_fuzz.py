@@ -68,7 +68,7 @@ def test_random_fir_filters(G, taps):
         d = gbank.fir_design(b, partial=partial)
         ys_g, ys_o, gb, ob = G.run_pair([d], [0] * nch, blocks, mode, seed=300 + taps + draw)
         yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
-        if mode == gbank.MODE_SEQUENTIAL or taps < 17:
+        if mode == gbank.MODE_SEQUENTIAL or taps < 2:          # AUTO: matrix-core kernel from 2 taps up
             assert util.bits_equal(yg, yo), (taps, partial, nch, blocks)
         else:
             assert float(np.max(util.rel_to_peak(yg, yo))) <= TOL, (taps, partial, nch, blocks)
