@@ -1889,25 +1889,19 @@ int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t
     const size_t ld = (size_t)gm.state_ld;
 
     /* run-ups: channel c-1 of `warm` filters the M samples in front of sub-chunk c from the zero state */
-    HIP_TRY(hipMemsetAsync(gw.d_state, 0, (C - 1) * ld * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(gw.d_init, 0, (C - 1) * sizeof(int32_t), s));
+    HIP_TRY(launch_split_zero(gw.d_state, gw.d_init, C - 1, (int)ld, s));
     rc = RTFilterBank_updaten(sb->warm, st->d_scratch, M, in + (Lc - M), Lc, M, s);
     if (rc) return rc;
 
     /* start states: sub-chunk 0 takes the carried state, sub-chunk c the end state of run-up c-1 */
-    HIP_TRY(hipMemcpyAsync(gm.d_state, g1.d_state, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(gm.d_fval, g1.d_fval, sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(gm.d_init, 0, C * sizeof(int32_t), s));
-    HIP_TRY(hipMemcpyAsync(gm.d_init, g1.d_init, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(gm.d_state + ld, gw.d_state, (C - 1) * ld * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, gw.d_state, C, (int)ld,
+                              1, 1, s));
 
     rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s);
     if (rc) return rc;
 
     /* the stream's state is what the last sub-chunk ended in */
-    HIP_TRY(hipMemcpyAsync(g1.d_state, gm.d_state + (C - 1) * ld, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g1.d_fval, gm.d_fval + (C - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(g1.d_init, 0, sizeof(int32_t), s));
+    HIP_TRY(launch_split_finish(g1.d_state, g1.d_fval, g1.d_init, gm.d_state, gm.d_fval, C, (int)ld, s));
     return RTFB_OK;
 }
 
@@ -1967,20 +1961,16 @@ int stream_split_piece_exact(RTFilterStream *st, double *out, const double *in, 
     const size_t ld = (size_t)gm.state_ld;
     const int N = (int)st->a.size() - 1;
 
-    HIP_TRY(hipMemsetAsync(gw.d_state, 0, (C - 1) * ld * sizeof(double), s));
-    HIP_TRY(hipMemsetAsync(gw.d_init, 0, (C - 1) * sizeof(int32_t), s));
+    HIP_TRY(launch_split_zero(gw.d_state, gw.d_init, C - 1, (int)ld, s));
     if ((rc = RTFilterBank_updaten(sb->warm, out, Lc, in, Lc, Lc, s))) return rc;
 
-    HIP_TRY(hipMemcpyAsync(gm.d_state, g1.d_state, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(gm.d_fval, g1.d_fval, sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(gm.d_init, 0, C * sizeof(int32_t), s));
+    HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, gw.d_state, C, (int)ld,
+                              0, 0, s));
     HIP_TRY(launch_compose_states(gm.d_state, ld, g1.d_state, gw.d_state, ld, d_M, N, (int)C, 1, s));
 
     if ((rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s))) return rc;
 
-    HIP_TRY(hipMemcpyAsync(g1.d_state, gm.d_state + (C - 1) * ld, ld * sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(g1.d_fval, gm.d_fval + (C - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(g1.d_init, 0, sizeof(int32_t), s));
+    HIP_TRY(launch_split_finish(g1.d_state, g1.d_fval, g1.d_init, gm.d_state, gm.d_fval, C, (int)ld, s));
     return RTFB_OK;
 }
 

@@ -98,6 +98,12 @@ hipError_t launch_state_unpack(const double *pack, double *state, double *fval, 
                                hipStream_t s);
 hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0, const double *v, size_t v_ld,
                                  const double *M, int N, int count, int write_all, hipStream_t s);
+hipError_t launch_split_zero(double *state, int32_t *init, size_t count, int ld, hipStream_t s);
+hipError_t launch_split_seed(double *state, double *fval, int32_t *init, const double *one_state, const double *one_fval,
+                             const int32_t *one_init, const double *warm, size_t count, int ld, int with_warm,
+                             int keep_init, hipStream_t s);
+hipError_t launch_split_finish(double *one_state, double *one_fval, int32_t *one_init, const double *state,
+                               const double *fval, size_t count, int ld, hipStream_t s);
 hipError_t launch_transpose(double *dst, size_t ld_dst, const double *src, size_t ld_src, size_t rows, size_t cols,
                             hipStream_t s);
 bool iir_scan_supported(int order);

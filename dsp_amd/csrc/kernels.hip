@@ -833,6 +833,42 @@ compose_states_kernel(double *dst, size_t dst_ld, const double *src0, const doub
     if (!write_all && i <= N) dst[i] = sbuf[cur][i];
 }
 
+/* Glue of the time split (RTFilterStream, bank.hip): the state shuffles around its two launches as ONE small
+ * kernel each instead of runs of one-element copies and memsets (ten ~4 us operations per 3.5 ms step). */
+__global__ void __launch_bounds__(256)
+split_zero_kernel(double *state, int32_t *init, size_t count, int ld)          /* before the run-up launch */
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count * (size_t)ld) state[i] = 0.0;
+    if (i < count) init[i] = 0;
+}
+
+/* before the main launch: sub-chunk 0 takes the stream's carried (state, fval, init); sub-chunk c >= 1 the end
+ * state of run-up c-1 (rows of `warm`), init 0; `with_warm` = 0 leaves rows 1.. to compose_states_kernel */
+__global__ void __launch_bounds__(256)
+split_seed_kernel(double *state, double *fval, int32_t *init, const double *one_state, const double *one_fval,
+                  const int32_t *one_init, const double *warm, size_t count, int ld, int with_warm, int keep_init)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)ld) state[i] = one_state[i];
+    else if (with_warm && i < count * (size_t)ld) state[i] = warm[i - ld];
+    if (i < count) init[i] = (i == 0 && keep_init) ? one_init[0] : 0;
+    if (i == 0) fval[0] = one_fval[0];
+}
+
+/* after it: the stream's state is what the last sub-chunk ended in */
+__global__ void __launch_bounds__(64)
+split_finish_kernel(double *one_state, double *one_fval, int32_t *one_init, const double *state, const double *fval,
+                    size_t count, int ld)
+{
+    const int i = threadIdx.x;
+    for (int k = i; k < ld; k += 64) one_state[k] = state[(count - 1) * (size_t)ld + k];
+    if (i == 0) {
+        one_fval[0] = fval[count - 1];
+        one_init[0] = 0;
+    }
+}
+
 /* dst[c * ld_dst + r] = src[r * ld_src + c], r < rows, c < cols: 32 x 32 tiles through LDS (padded), coalesced on
  * both sides.  Turns time-major frames (one sample per channel) into the channel-major rows the filters read, and
  * back (RTFilterBankFeed). */
@@ -1022,6 +1058,31 @@ hipError_t launch_compose_states(double *dst, size_t dst_ld, const double *src0,
     if (N < 1 || N > 16 || count < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(compose_states_kernel, dim3(1), dim3(kWave), 0, s, dst, dst_ld, src0, v, v_ld, M, N, count,
                        write_all);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_zero(double *state, int32_t *init, size_t count, int ld, hipStream_t s)
+{
+    const size_t n = count * (size_t)ld;
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(split_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, state, init, count, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_seed(double *state, double *fval, int32_t *init, const double *one_state, const double *one_fval,
+                             const int32_t *one_init, const double *warm, size_t count, int ld, int with_warm,
+                             int keep_init, hipStream_t s)
+{
+    const size_t n = count * (size_t)ld;
+    hipLaunchKernelGGL(split_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, state, fval, init,
+                       one_state, one_fval, one_init, warm, count, ld, with_warm, keep_init);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_finish(double *one_state, double *one_fval, int32_t *one_init, const double *state,
+                               const double *fval, size_t count, int ld, hipStream_t s)
+{
+    hipLaunchKernelGGL(split_finish_kernel, dim3(1), dim3(64), 0, s, one_state, one_fval, one_init, state, fval, count, ld);
     return hipGetLastError();
 }
 
