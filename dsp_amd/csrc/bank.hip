@@ -634,12 +634,14 @@ constexpr ProbeKernel kProbeScan2 = {kScan2T, kScan2Rows, false};  /* iir_scan2_
 constexpr ProbeKernel kProbeScan16 = {kScanT, kWave, false};       /* iir_scan16_kernel, orders 9..16                */
 
 /* pw: nlev_table matrices A^(T 2^k), row-major; gtab: G[n][i], n < T, then Gc[i]; ttab: [e][j] (R = 64) or null */
-template <bool kHwFma>
+/* NN: the order as a compile-time constant (0 = any): the loops over the states then unroll and vectorise --
+ * the probe is what a bank of many distinct designs spends its set-up time in. */
+template <bool kHwFma, int NN>
 static inline __attribute__((always_inline)) double scan_probe_body(const Design &d, const ProbeKernel &pk,
                                                                     const double *pw, int nlev, const double *gtab,
                                                                     const double *ttab)
 {
-    const int N = d.nb - 1, T = pk.T, R = pk.R, L = 2 * R * T, S = N + 1;
+    const int N = NN ? NN : d.nb - 1, T = pk.T, R = pk.R, L = 2 * R * T, S = N + 1;
     std::vector<double> x(L), yref(L), y(L);
     uint64_t z = 0x243F6A8885A308D3ull;
     for (int k = 0; k < L; ++k) {                /* splitmix64 stream in [-1, 1) */
@@ -736,22 +738,38 @@ static inline __attribute__((always_inline)) double scan_probe_body(const Design
 /* hipcc builds host code for baseline x86-64, where __builtin_fma is a libm call (~5 ns): the probe of one
  * design then takes over a millisecond and a bank of 65 536 distinct designs tens of seconds.  Hosts with FMA
  * units (every host of an MI355X) take the instantiation compiled for them; same IEEE results either way. */
-__attribute__((target("fma"))) double scan_probe_hw(const Design &d, const ProbeKernel &pk, const double *pw, int nlev,
-                                                    const double *gtab, const double *ttab)
+template <bool kHw>
+static inline __attribute__((always_inline)) double scan_probe_by_order(const Design &d, const ProbeKernel &pk,
+                                                                        const double *pw, int nlev, const double *gtab,
+                                                                        const double *ttab)
 {
-    return scan_probe_body<true>(d, pk, pw, nlev, gtab, ttab);
+    switch (d.nb - 1) {
+        case 2: return scan_probe_body<kHw, 2>(d, pk, pw, nlev, gtab, ttab);
+        case 4: return scan_probe_body<kHw, 4>(d, pk, pw, nlev, gtab, ttab);
+        case 6: return scan_probe_body<kHw, 6>(d, pk, pw, nlev, gtab, ttab);
+        case 8: return scan_probe_body<kHw, 8>(d, pk, pw, nlev, gtab, ttab);
+        case 12: return scan_probe_body<kHw, 12>(d, pk, pw, nlev, gtab, ttab);
+        case 16: return scan_probe_body<kHw, 16>(d, pk, pw, nlev, gtab, ttab);
+        default: return scan_probe_body<kHw, 0>(d, pk, pw, nlev, gtab, ttab);
+    }
+}
+
+__attribute__((target("fma,avx2"))) double scan_probe_hw(const Design &d, const ProbeKernel &pk, const double *pw, int nlev,
+                                                         const double *gtab, const double *ttab)
+{
+    return scan_probe_by_order<true>(d, pk, pw, nlev, gtab, ttab);
 }
 
 double scan_probe_sw(const Design &d, const ProbeKernel &pk, const double *pw, int nlev, const double *gtab,
                      const double *ttab)
 {
-    return scan_probe_body<false>(d, pk, pw, nlev, gtab, ttab);
+    return scan_probe_by_order<false>(d, pk, pw, nlev, gtab, ttab);
 }
 
 double scan_probe(const Design &d, const ProbeKernel &pk, const double *pw, int nlev, const double *gtab,
                   const double *ttab)
 {
-    static const bool hw = __builtin_cpu_supports("fma");
+    static const bool hw = __builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2");
     return hw ? scan_probe_hw(d, pk, pw, nlev, gtab, ttab) : scan_probe_sw(d, pk, pw, nlev, gtab, ttab);
 }
 
