@@ -221,3 +221,41 @@ def test_fir_short_blocks_on_a_wide_bank_lane_per_channel(G, mode_name, layout):
         assert np.all(util.rel_to_peak(yg, yo) <= TOL_MFMA)
     st = gb.get_state()[0]
     assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state)
+
+
+@pytest.mark.parametrize("taps", [254, 255, 256, 1008, 1023, 1024, 1025, 4090, 4096])
+def test_mfma_head_shared_between_edge_and_persistent_kernel(G, taps):
+    """The persistent matrix-core kernel takes over at the first multiple of 256 with more than K samples behind
+    it; the edge kernel writes what lies before.  Tap counts around the tile (256), the one-tile-per-wavefront
+    limit (1024) and the item size (4096), stable and ramp initialisation, blocks that do / do not hold a whole
+    item, consecutive blocks with the state carried.  AUTO within 1e-12 of the oracle, delay line bit-exact."""
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(7000 + taps)
+    b = rng.standard_normal(taps) / taps ** 0.5
+    for partial in (False, True):
+        d = gbank.fir_design(b, partial=partial)
+        blocks = [8192 + 300, 4096, 3000, 12288, 1]
+        ys_g, ys_o, gb, ob = G.run_pair([d], [0, 0, 0], blocks, gbank.MODE_AUTO, seed=taps)
+        yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+        assert float(np.max(util.rel_to_peak(yg, yo))) <= TOL_MFMA, (taps, partial)
+        st = gb.get_state()[0]
+        assert util.bits_equal(st[:, :taps], ob.state[:, :taps]), (taps, partial)
+        gb.close()
+
+
+def test_mfma_head_in_a_group_of_mixed_lengths_and_initialisers(G):
+    """One FIR launch group with filters of 5 .. 1030 taps, stable and partial_init: the hand-over point is the
+    group's (longest filter), ramp channels are handed over at the end of the exact head kernel's segments."""
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(77)
+    designs = [gbank.fir_design(rng.standard_normal(5) / 3), gbank.fir_design(np.full(300, 1.0 / 300), partial=True),
+               gbank.fir_design(rng.standard_normal(300) / 17), gbank.fir_design(rng.standard_normal(1030) / 32, partial=True),
+               gbank.fir_design(rng.standard_normal(33) / 6, partial=True)]
+    nch = 37
+    idx = [(3 * c + c // 5) % len(designs) for c in range(nch)]
+    ys_g, ys_o, gb, ob = G.run_pair(designs, idx, [3000, 8192 + 77, 4096, 1, 20000], gbank.MODE_AUTO, seed=78)
+    yg, yo = np.concatenate(ys_g, axis=1), np.concatenate(ys_o, axis=1)
+    assert float(np.max(util.rel_to_peak(yg, yo))) <= TOL_MFMA
+    st, fv, ini = gb.get_state()
+    assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state) and np.array_equal(ini, ob.init)
+    gb.close()
