@@ -312,6 +312,9 @@ fir_epilogue_kernel(GroupView g, BlockIO io)
 
     /* the last min(regular, K-1) inputs, newest first (xl[j] = x[n-j]); the taps at pitch R+1 per R
      * (lanes read them R apart), zero beyond K-1 (never used: those steps are predicated off) */
+    /* (xl stays dense although lanes walk their chains 8 steps apart -- xl[j] is a read at a stride of 8 doubles,
+     * 8 lanes per bank, the 4.6e8 SQ_LDS_BANK_CONFLICT cycles per launch at 512 taps: skewing it like bl removes
+     * the conflicts and costs more in per-step address arithmetic than they do, 1.41 -> 1.52 ms, round 2) */
     double *xl = lds;
     double *bl = lds + K;
     const int depth = regular < K - 1 ? (int)regular : K - 1;

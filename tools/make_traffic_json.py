@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""profiles/r1_traffic.json and profiles/r1_fir512_traffic.json from the tools/prof.sh summaries
-(profiles/r1_config{2,3,5}_rocprofv3_summary.txt)."""
+"""profiles/<round>_traffic.json, <round>_fir512_traffic.json and <round>_config5_traffic.json from the tools/prof.sh
+summaries (profiles/<round>_config{2,3,5}_rocprofv3_summary.txt).  usage: make_traffic_json.py [r2]"""
 import json
 import os
 import re
 
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RND = sys.argv[1] if len(sys.argv) > 1 else "r2"        # profile prefix: r1, r2, ...
 CORR = ("MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) "
         "coalesced streaming read -> doubled; WRITE_SIZE exact for 16 B/lane streaming stores")
 
@@ -31,26 +33,26 @@ def pick(per, needle):
 
 
 def main():
-    s2 = sections(os.path.join(ROOT, "profiles", "r1_config2_rocprofv3_summary.txt"))
+    s2 = sections(os.path.join(ROOT, "profiles", RND + "_config2_rocprofv3_summary.txt"))
     f = pick(s2["pmc_fetch"], "iir_pipe_kernel<8, true")[0]["FETCH_SIZE"]
     w = pick(s2["pmc_write"], "iir_pipe_kernel<8, true")[0]["WRITE_SIZE"]
     hbm = int(f * 1024 * 2 + w * 1024)
     alg = 1024 * 65536 * 16
     json.dump({"kernel": "dsp::iir_pipe_kernel<8, true, true>",
-               "source": "profiles/r1_config2_rocprofv3_summary.txt (tools/prof.sh: rocprofv3 --pmc FETCH_SIZE "
+               "source": "profiles/" + RND + "_config2_rocprofv3_summary.txt (tools/prof.sh: rocprofv3 --pmc FETCH_SIZE "
                          "GRBM_GUI_ACTIVE ; --pmc WRITE_SIZE ; bench.py --steps 32 --warmup 8 --no-cpu)",
                "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "correction": CORR,
                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
                "traffic_over_algorithmic": hbm / alg},
-              open(os.path.join(ROOT, "profiles", "r1_traffic.json"), "w"), indent=1)
-    s3 = sections(os.path.join(ROOT, "profiles", "r1_config3_rocprofv3_summary.txt"))
+              open(os.path.join(ROOT, "profiles", RND + "_traffic.json"), "w"), indent=1)
+    s3 = sections(os.path.join(ROOT, "profiles", RND + "_config3_rocprofv3_summary.txt"))
     tot_f = sum(v["FETCH_SIZE"] for k, v in s3["pmc_fetch"].items() if "fir_" in k)
     tot_w = sum(v["WRITE_SIZE"] for k, v in s3["pmc_write"].items() if "fir_" in k)
     steady = pick(s3["pmc_mfma"], "fir_mfma_kernel<")[0]
     hbm3 = int(tot_f * 1024 * 2 + tot_w * 1024)
     alg3 = 65536 * 65536 * 16
     json.dump({"kernels": "fir_prologue + fir_mfma_edge + fir_mfma_kernel<true> + fir_epilogue (one step of config 3)",
-               "source": "profiles/r1_config3_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
+               "source": "profiles/" + RND + "_config3_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
                          "bench.py --workload fir512 --steps 3 --warmup 1 --no-cpu)",
                "FETCH_SIZE_KiB_per_step": tot_f, "WRITE_SIZE_KiB_per_step": tot_w, "correction": CORR,
                "hbm_bytes_per_launch": hbm3, "algorithmic_bytes_per_launch": alg3,
@@ -60,8 +62,8 @@ def main():
                "grbm_gui_active_steady_kernel_sum_over_8_xcd": steady["GRBM_GUI_ACTIVE"],
                "mfma_pipe_utilisation_steady_kernel":
                    steady["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * steady["GRBM_GUI_ACTIVE"] / 8)},
-              open(os.path.join(ROOT, "profiles", "r1_fir512_traffic.json"), "w"), indent=1)
-    s5 = sections(os.path.join(ROOT, "profiles", "r1_config5_rocprofv3_summary.txt"))
+              open(os.path.join(ROOT, "profiles", RND + "_fir512_traffic.json"), "w"), indent=1)
+    s5 = sections(os.path.join(ROOT, "profiles", RND + "_config5_rocprofv3_summary.txt"))
     f5 = pick(s5["pmc_fetch"], "iir_scan16_kernel")[0]["FETCH_SIZE"]
     w5 = pick(s5["pmc_write"], "iir_scan16_kernel")[0]["WRITE_SIZE"]
     m5 = pick(s5["pmc_mfma"], "iir_scan16_kernel")[0]
@@ -70,7 +72,7 @@ def main():
     json.dump({"kernel": "dsp::iir_scan16_kernel<16, 64, true, false>: mean over the two launches of a config-5 step "
                          "(run-up over the sub-chunks' 1024-sample tails + main launch over 2^30 samples), so that "
                          "2 x the per-launch figures = one step",
-               "source": "profiles/r1_config5_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
+               "source": "profiles/" + RND + "_config5_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
                          "bench.py --workload stream16 --no-cpu)",
                "FETCH_SIZE_KiB_per_launch": f5, "WRITE_SIZE_KiB_per_launch": w5, "correction": CORR,
                "hbm_bytes_per_launch": hbm5, "algorithmic_bytes_per_launch": alg5,
@@ -78,8 +80,8 @@ def main():
                "mfma_busy_cycles": m5["SQ_VALU_MFMA_BUSY_CYCLES"],
                "grbm_gui_active_sum_over_8_xcd": m5["GRBM_GUI_ACTIVE"],
                "mfma_pipe_utilisation": m5["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m5["GRBM_GUI_ACTIVE"] / 8)},
-              open(os.path.join(ROOT, "profiles", "r1_config5_traffic.json"), "w"), indent=1)
-    for n in ("r1_traffic.json", "r1_fir512_traffic.json", "r1_config5_traffic.json"):
+              open(os.path.join(ROOT, "profiles", RND + "_config5_traffic.json"), "w"), indent=1)
+    for n in (RND + "_traffic.json", RND + "_fir512_traffic.json", RND + "_config5_traffic.json"):
         print(n, json.load(open(os.path.join(ROOT, "profiles", n)))["traffic_over_algorithmic"])
 
 
