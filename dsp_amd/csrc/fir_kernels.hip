@@ -1059,9 +1059,14 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         const long long ramp_first = g.has_partial ? (long long)nhead * S : 0;
         if (nedge > 0) {
             /* only short heads (no whole edge item in front of them, no ragged end behind): one tile per wavefront */
-            if (shared_head && nedge == 1 && head_out <= 256 * kMfmaWaves)
-                hipLaunchKernelGGL(fir_mfma_edge_kernel<1>, dim3(nedge, g.count), dim3(kMfmaWaves * kWave), mfma_lds,
+            if (shared_head && nedge == 1 && head_out <= 256 * kMfmaWaves) {
+                /* LDS for what a head stages (taps, history, head_out + 16 inputs), not for a whole item: two to
+                 * three times as many workgroups per CU overlap their staging with the others' contraction */
+                const int htotal = hist + (int)head_out + 16;
+                const size_t head_lds = (size_t)(hist + 32 + htotal + 2 * (htotal >> 4) + 2) * sizeof(double);
+                hipLaunchKernelGGL(fir_mfma_edge_kernel<1>, dim3(nedge, g.count), dim3(kMfmaWaves * kWave), head_lds,
                                    s, g, io, (long long)nhead * S, edge_lo, steady_hi, head_out);
+            }
             else
                 hipLaunchKernelGGL(fir_mfma_edge_kernel<kMfmaTiles>, dim3(nedge, g.count), dim3(kMfmaWaves * kWave),
                                    mfma_lds, s, g, io, (long long)nhead * S, edge_lo, steady_hi, head_out);
