@@ -294,7 +294,6 @@ def main():
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
                        "layout": args.layout, "row_pitch_doubles": pitch, "settle_steps_untimed": settle_steps,
-                       "buffers": "x @ %#x, y @ %#x" % (xbuf.data_ptr(), ybuf.data_ptr()),
                        "distinct_designs": CHANNELS if args.jitter else 1,
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
