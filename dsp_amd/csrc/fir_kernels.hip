@@ -609,11 +609,16 @@ struct MfmaItem {
     int emin;               /* first staged element that exists (> 0 only in the item that holds the block's
                                first samples: what lies before them only ever meets outputs that are skipped) */
     long long first;        /* block-local index of the first output this kernel writes for the channel */
+    /* folded head (the block's first item, groups without partial_init channels): its first K-1 outputs sit on
+     * the carried state instead of s[K-1], and what lies before the first regular sample t0 contributes nothing */
+    bool head;
+    int t0;                 /* 1 when stable_init consumed sample 0 of this block (the prologue wrote its output) */
+    const double *st;       /* the channel's carried state s[0..K-1] */
 };
 
 
 __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg,
-                                              long long head_out, long long ramp_first)
+                                              long long head_out, long long ramp_first, bool fold)
 {
     MfmaItem it;
     const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
@@ -627,9 +632,12 @@ __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO 
     const long long last = (long long)io.n - 1 - (seg_base - it.hist);
     it.emax = last < it.hist + kMfmaSeg + 15 ? (int)last : it.hist + kMfmaSeg + 15;
     it.out = io.out + (size_t)chan * io.ld_out + seg_base;
-    it.tail = as_const(g.state + (size_t)gi * g.state_ld)[it.K - 1];   /* written by an earlier kernel */
+    it.st = g.state + (size_t)gi * g.state_ld;
+    it.tail = as_const(it.st)[it.K - 1];            /* written by an earlier kernel */
     it.emin = seg_base < it.hist ? (int)(it.hist - seg_base) : 0;
     it.first = head_out;
+    it.head = fold && seg == 0;
+    it.t0 = it.head ? as_const(g.aux)[2 * gi] : 0;  /* written by the prologue kernel */
     if (ramp_first > head_out) {                    /* groups with partial_init channels: g.aux is this launch's */
         const bool ramp = as_const(g.kind)[it.dsn] == RTFB_KIND_FIR_PARTIAL && g.aux[2 * gi + 1] < it.K;
         if (ramp) it.first = ramp_first;            /* the exact head kernel wrote everything before it */
@@ -663,7 +671,8 @@ __device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *
  * are in flight together and nothing makes the compiler drain vmcnt inside the item loop. */
 template <bool kAligned16>
 __global__ void __launch_bounds__(kMfmaWaves * kWave, 3)      /* 3 waves per SIMD: <= 168 VGPRs */
-fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long head_out, long long ramp_first)
+fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long head_out, long long ramp_first,
+                int fold)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);
@@ -681,7 +690,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
     int gi = (int)(idx / nseg);
     int seg = (int)(idx - (long long)gi * nseg);
 
-    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg, head_out, ramp_first);
+    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg, head_out, ramp_first, kAligned16 && fold != 0);
     /* emax is odd here (hist + 4096 - 1 when the block ends with the item, else hist + 4096 + 15), so a pair
      * clamped to emax >> 1 never reaches past it; clamped positions only ever meet zero taps */
     double xr[kMfmaPre];
@@ -709,18 +718,50 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
         double *xs = lds + nb_pad;
         const int total = cur.hist + kMfmaSeg + 16;             /* inputs seg_base-hist .. seg_base+4096+15 */
 
+        /* head items: x[0] - s[K-1] and s[0..K-2] - s[K-1], behind the item's inputs (in a steady item the
+         * staging below runs over that place: it writes whole rounds of the prefetch) */
+        double *sa = xs + xpos(total) + 2;
+
         lds_barrier();                                        /* the previous item's operand reads are over */
         /* (first, so that the wait is for the prefetch only: the previous item's stores are younger) */
-        if constexpr (kAligned16) {
+        if (!cur.head) {
+            if constexpr (kAligned16) {
 #pragma unroll
-            for (int k = 0; k < kMfmaPre2; ++k)            /* elements 2p, 2p+1 share a 16-group: one 16-byte write */
-                *reinterpret_cast<d2 *>(xs + xpos(2 * (tid + kThreads * k))) = xr2[k];
+                for (int k = 0; k < kMfmaPre2; ++k)        /* elements 2p, 2p+1 share a 16-group: one 16-byte write */
+                    *reinterpret_cast<d2 *>(xs + xpos(2 * (tid + kThreads * k))) = xr2[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
+            }
+            for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
+                xs[xpos(e)] = cur.x0[max(min(e, cur.emax), cur.emin)];
         } else {
+            /* The block's first item: zeros where there is no regular sample (before t0), nothing written past
+             * the item's inputs, and the state loaded here, where the prefetch registers are free again -- the
+             * other workgroups of the CU keep the matrix cores busy meanwhile. */
+            const int zmin = cur.hist + cur.t0;
+            if constexpr (kAligned16) {
 #pragma unroll
-            for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
+                for (int k = 0; k < kMfmaPre2; ++k) {
+                    const int e = 2 * (tid + kThreads * k);
+                    d2 v = xr2[k];
+                    v.x = e < zmin ? 0.0 : v.x;
+                    v.y = e + 1 < zmin ? 0.0 : v.y;
+                    if (e < total) *reinterpret_cast<d2 *>(xs + xpos(e)) = v;      /* total is even */
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kMfmaPre; ++k) {
+                    const int e = tid + kThreads * k;
+                    if (e < total) xs[xpos(e)] = e < zmin ? 0.0 : xr[k];
+                }
+            }
+            for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads) {
+                const double v = cur.x0[max(min(e, cur.emax), cur.emin)];
+                xs[xpos(e)] = e < zmin ? 0.0 : v;
+            }
+            for (int e = tid; e < cur.K; e += kThreads) sa[e] = (e == 0 ? cur.x0[cur.hist] : cur.st[e - 1]) - cur.tail;
         }
-        for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
-            xs[xpos(e)] = cur.x0[max(min(e, cur.emax), cur.emin)];
         if (cur.dsn != staged_dsn) {
             for (int e = tid; e < nb_pad; e += kThreads) {
                 const int k = e - 16;
@@ -744,8 +785,9 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
             if (++seg == nseg) {                                /* next channel: a chain of scalar loads */
                 seg = 0;
                 ++gi;
-                nxt = mfma_item(g, io, gi, steady_lo, head_out, ramp_first);
+                nxt = mfma_item(g, io, gi, steady_lo, head_out, ramp_first, kAligned16 && fold != 0);
             } else {                                            /* next segment of the same channel */
+                nxt.head = false;
                 nxt.x0 += kMfmaSeg;
                 nxt.out += kMfmaSeg;
                 const long long nb = (long long)(steady_lo + seg) * kMfmaSeg;
@@ -756,6 +798,9 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
             seg_base = (long long)(steady_lo + seg) * kMfmaSeg;
             prefetch(nxt);
         }
+        /* the next item's scalar loads end here: one pending into the contraction loop puts an lgkmcnt(0) at
+         * its head (scalar loads return out of order), which every iteration would pay */
+        asm volatile("" :: "s"(nxt.tail), "s"(nxt.t0));
 
 #pragma unroll
         for (int t = 0; t < kMfmaTiles; ++t) acc[t] = (d4){cur.tail, cur.tail, cur.tail, cur.tail};
@@ -788,6 +833,26 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) mfma_apply<kMfmaTiles>(acc, r, u);
+
+        /* Outputs t0 .. t0 + K - 2 of a head item sit on s[m - t0], not on s[K-1] (output 0 on x[0] when
+         * stable_init consumed it: the contraction added exact zeros to a zero tail there).  Added here, in
+         * place and in a wave-uniform branch, instead of at the initialisation: a conditional definition of
+         * the accumulator tuples spills, and anything in front of the contraction lengthens the stretch in
+         * which the workgroup issues no MFMA -- for every item. */
+        if (cur.head) {
+#pragma unroll
+            for (int t = 0; t < kMfmaTiles; ++t) {
+                const int mi0 = 256 * (kMfmaTiles * wave + t) + 1 - cur.t0;
+                if (mi0 <= cur.K - 1) {                         /* wave-uniform: later tiles are steady */
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int mi = mi0 + 16 * j + 4 * q + r4;
+                        const double c = sa[min(mi, cur.K - 1)];
+                        acc[t][r4] += mi <= cur.K - 1 ? c : 0.0;
+                    }
+                }
+            }
+        }
 
         pending = cur.out + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
         pending_skip = cur_skip;
@@ -1035,7 +1100,12 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         const int hist = 16 * (mfma_steps16(g.kmax) - 1);
         int xtotal = hist + kMfmaSeg + 16;
         if (xtotal < kMfmaPreElems) xtotal = kMfmaPreElems;
-        const size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
+        size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
+        {   /* a folded head keeps K state words behind its inputs (mostly inside the slack of the line above) */
+            const int ptotal = hist + kMfmaSeg + 16;
+            const size_t with_state = (size_t)(hist + 32 + ptotal + 2 * (ptotal >> 4) + 2 + g.kmax) * sizeof(double);
+            if (with_state > mfma_lds) mfma_lds = with_state;
+        }
         const int nwg = (int)((io.n + kMfmaSeg - 1) / kMfmaSeg);       /* segments per channel */
         /* steady segments: first output has more than kmax samples behind it (and lies past any
          * ramp head: nhead*S <= steady_lo*kMfmaSeg), the whole segment is inside the block */
@@ -1048,7 +1118,14 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         long long head_out = 256LL * ((g.kmax + 1 + 255) / 256);
         int steady_lo = (int)(head_out / kMfmaSeg);                 /* the item that holds head_out */
         int steady_hi = (int)(io.n / kMfmaSeg);
-        if (steady_lo >= steady_hi) {                               /* short block: no item is whole */
+        /* Groups without partial_init channels: the persistent kernel takes the head as well -- its first item
+         * starts from the carried state, with zeros where there is no regular sample before the block. */
+        /* (aligned rows only: the other instantiation is at its register limit) */
+        const bool fold = !g.has_partial && steady_hi > 0 && io.aligned16;
+        if (fold) {
+            head_out = 0;
+            steady_lo = 0;
+        } else if (steady_lo >= steady_hi) {                        /* short block: no item is whole */
             steady_lo = steady_hi = steady_lo < nwg ? steady_lo : nwg;
             if (steady_hi > (int)(io.n / kMfmaSeg)) steady_hi = steady_lo = (int)(io.n / kMfmaSeg);
             head_out = 0;                                           /* nothing is shared */
@@ -1078,10 +1155,10 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
             if (grid > items) grid = items;
             if (io.aligned16)
                 hipLaunchKernelGGL(fir_mfma_kernel<true>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first);
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0);
             else
                 hipLaunchKernelGGL(fir_mfma_kernel<false>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first);
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
