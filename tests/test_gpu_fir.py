@@ -259,3 +259,42 @@ def test_mfma_head_in_a_group_of_mixed_lengths_and_initialisers(G):
     st, fv, ini = gb.get_state()
     assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state) and np.array_equal(ini, ob.init)
     gb.close()
+
+
+def test_mfma_folded_head_with_an_injected_state(G):
+    """Groups without partial_init channels: the persistent kernel takes the block's first item too, starting its
+    first K-1 outputs from the carried state.  Mixed lengths (below and above the 753-tap prefetch limit), the first
+    block after stable_init, then a state injected by hand with a NONZERO s[K-1] (read, never written by the update:
+    ref src/RTFilter.c:235-247), blocks of exactly one item and ragged ones."""
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(79)
+    taps = [40, 513, 300, 900]
+    designs = [gbank.fir_design(rng.standard_normal(k) / k ** 0.5) for k in taps]
+    nch = 11
+    idx = [c % len(designs) for c in range(nch)]
+    gb = gbank.FilterBank(designs, idx, mode=gbank.MODE_AUTO)
+    from oracle import oracle as orc
+    ob = orc.Bank([G.to_orc_design(d) for d in designs], idx)
+    pos = 0
+
+    def step(n):
+        nonlocal pos
+        x = G.make_inputs(80, nch, n, pos)
+        pos += n
+        yg, yo = gb(G.to_dev(x)).cpu().numpy(), ob.updaten(x, threads=4)
+        assert float(np.max(util.rel_to_peak(yg, yo))) <= TOL_MFMA, n
+        st, fv, ini = gb.get_state()
+        assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state) and np.array_equal(ini, ob.init), n
+
+    for n in (5000, 4096):
+        step(n)
+    st, fv, ini = gb.get_state()
+    inj = rng.standard_normal(ob.state.shape)
+    for c in range(nch):
+        inj[c, taps[idx[c]]:] = 0.0                           # beyond the channel's own K: not state
+    st[:, :ob.state.shape[1]] = inj
+    gb.set_state(st, fv, ini)
+    ob.state[:] = inj
+    for n in (4096, 8192 + 5, 4096, 20000):
+        step(n)
+    gb.close()
