@@ -544,6 +544,24 @@ def main_mixed(args):
         elapsed = float(t.item())
     step_ms = np.array([e0.elapsed_time(e1) for e0, e1 in events])
     avg_s = float(np.mean(step_ms)) / 1e3
+    # Streaming-copy ceiling for the wave's shape and footprint (65 536 rows x 64K, 32 GiB each way): the
+    # compute-free twin of the kernels' access pattern on the very buffers.  Untimed extra, rank 0 only.
+    copy_gbs = None
+    if rank == 0:
+        import ctypes as C
+        from dsp_amd.cdsp import dspdll
+        cts = []
+        for k in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = dspdll.dsp_copy_rows(C.c_void_p(ybufs[0].data_ptr()), pitch, C.c_void_p(x.data_ptr()), pitch, wave, BLOCK,
+                                      256, 8192, C.c_void_p(stream.cuda_stream))
+            e1.record(stream)
+            torch.cuda.synchronize()
+            if rc == 0 and k >= 1:
+                cts.append(e0.elapsed_time(e1))
+        if cts:
+            copy_gbs = wave * BLOCK * BYTES_PER_SAMPLE / (float(np.median(cts)) / 1e3) / 1e9
     if rank == 0:
         samples = wave * BLOCK
         achieved = samples * BYTES_PER_SAMPLE / avg_s / 1e9
@@ -567,6 +585,8 @@ def main_mixed(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
+                         "copy_ceiling_measured": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "note": "all kernels of one RTFilterBank_updaten over one wave, rank 0's device time per call",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
