@@ -376,6 +376,101 @@ fir_epilogue_kernel(GroupView g, BlockIO io)
     }
 }
 
+/* End state of blocks that hold at least K-1 regular samples (every chain runs its full length from s[K-1]):
+ * the same chains, same order of operations, aligned on the TAP instead of on the sample.
+ *     s'[i] = ((s[K-1] + b[K-1] x[n-(K-1-i)]) + b[K-2] x[n-(K-2-i)]) + ... + b[i+1] x[n-1]
+ * At tap k chain i takes xl[k-i] (xl[j] = x[n-j]); every chain of the block starts at tap K-1 and chain i ends at
+ * tap i+1.  A wavefront takes 128 consecutive chains of one channel (a PASS; lane = 2 consecutive chains), so its
+ * lanes run nearly the same number of steps -- in fir_epilogue_kernel a lane owns 8 chains out of all K-1 and the
+ * wavefront runs as long as the longest of them, half of the lane-steps idle.  The tap is wave-uniform: 16 at a
+ * time through scalar loads; the 18 samples a lane needs for 16 steps arrive as nine 16-byte LDS reads at a lane
+ * pitch of 16 bytes (conflict-free).  Steps outside the aligned 16-blocks (before the first, after a lane's last)
+ * go one at a time with the tap from LDS.  Every product and sum is rounded separately, as in the reference. */
+constexpr int kEpiTapR = 2;                               /* chains per lane */
+constexpr int kEpiTapPass = kEpiTapR * kWave;            /* chains per wavefront */
+
+__global__ void __launch_bounds__(kWave)
+fir_epilogue_taps_kernel(GroupView g, BlockIO io)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *lds = reinterpret_cast<double *>(smem_raw);
+
+    const int lane = threadIdx.x;
+    const int gi = blockIdx.y;
+    const int c0 = (int)blockIdx.x * kEpiTapPass;            /* first chain of this pass */
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+    const int K = as_const(g.nb)[dsn];
+    if (c0 > 0 && c0 >= K - 1) return;                        /* (pass 0 always runs: it keeps the books) */
+    const double *b = g.coefs + as_const(g.coef_off)[dsn];
+    cdouble_p cb = as_const(b);
+    const double *s_in = g.state + (size_t)gi * g.state_ld;
+    double *s_out = g.state_out + (size_t)gi * g.state_ld;
+    const long long n = (long long)io.n;
+    const double *x = io.in + (size_t)chan * io.ld_in;
+    const double tail = as_const(s_in)[K - 1];
+
+    /* xl[j] = x[n-j] for j = 1 .. K-1-c0 (what chain c0 reaches back to), xl[0] a readable dummy; then the taps */
+    const int jmax = K - 1 - c0;
+    double *xl = lds;
+    double *bl = lds + ((jmax + 2) & ~1);
+    for (int j = lane; j <= jmax; j += kWave) xl[j] = j >= 1 ? x[n - j] : 0.0;
+    for (int k = lane; k < K; k += kWave) bl[k] = b[k];
+    wave_sync();
+
+    const int i0 = c0 + kEpiTapR * lane;                     /* this lane's chains: i0, i0 + 1 */
+    double acc0 = tail, acc1 = tail;
+    /* one tap for both chains; chain i is inside its run while i + 1 <= k (k <= K-1 always) */
+    auto single = [&](int k) {
+        const double t = bl[k];
+        const int j = k - i0;
+        const double x0 = xl[j > 0 ? j : 0], x1 = xl[j > 1 ? j - 1 : 0];
+        const double p0 = t * x0, p1 = t * x1;
+        acc0 = k >= i0 + 1 ? acc0 + p0 : acc0;
+        acc1 = k >= i0 + 2 ? acc1 + p1 : acc1;
+    };
+    int k = K - 1;
+    for (; (k & 15) != 15 && k > c0; --k) single(k);        /* wave-uniform: down to a block boundary */
+    /* 16 taps per trip while both chains of the lane need all of them; lanes leave one after the other, the
+     * ones still inside agree on k.  (Requesting the next block's operands before the arithmetic of the current
+     * one, in a second register set, was measured and is slower: 1.6 vs 1.24 ms at 512 taps -- the other
+     * wavefronts of the SIMD hide the wait better than the longer live ranges allow.) */
+    while (k - 15 >= i0 + 2) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        double t[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) t[m] = cb[ku - 15 + m];
+        const double *xp = xl + (k - i0 - 17);               /* even index: 16-byte aligned */
+        d2 xv[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) xv[m] = *reinterpret_cast<const d2 *>(xp + 2 * m);
+        auto xat = [&](int m) { return (m & 1) ? xv[m >> 1].y : xv[m >> 1].x; };
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {              /* tap k - sidx: x0 = xl[k-sidx-i0], x1 = the one before */
+            const double p0 = t[15 - sidx] * xat(17 - sidx);
+            const double p1 = t[15 - sidx] * xat(16 - sidx);
+            acc0 = acc0 + p0;
+            acc1 = acc1 + p1;
+        }
+        k -= 16;
+    }
+    for (; k >= i0 + 1; --k) single(k);                      /* the lane's last steps (its own k from here on) */
+
+    if (i0 <= K - 2) s_out[i0] = acc0;
+    if (i0 + 1 <= K - 2) s_out[i0 + 1] = acc1;
+    if (blockIdx.x == 0 && lane == 0) {
+        const int ramp0 = g.aux[2 * gi + 1];
+        s_out[K - 1] = tail;
+        g.fval[gi] = io.out[(size_t)chan * io.ld_out + n - 1];
+        int ini = 0;
+        if (as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL && ramp0 < K) {
+            const long long last = (long long)ramp0 + n - 1;    /* stream index of the last sample */
+            ini = last >= K - 1 ? 0 : (int)(K - 1 - last);
+        }
+        g.init[gi] = ini;
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Long-tap FIR as a Toeplitz-tile contraction on the FP64 matrix cores         */
 /* (v_mfma_f64_16x16x4_f64).  The other MFMA user is the order 9..16 IIR scan   */
@@ -1172,6 +1267,13 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
                                (size_t)(S + g.kmax + 2) * sizeof(double), s, g, io, nhead);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
+    }
+    if (io.n >= (size_t)g.kmax + 1 && g.kmax >= 2) {
+        /* every channel has its K-1 regular samples inside the block (one may have gone to stable_init) */
+        const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
+        const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
+        hipLaunchKernelGGL(fir_epilogue_taps_kernel, dim3(passes, g.count), dim3(kWave), lds_taps, s, g, io);
+        return hipGetLastError();
     }
     const size_t epi_lds = (size_t)(g.kmax + (g.kmax + kEpiR) + (g.kmax + kEpiR) / kEpiR + 2) * sizeof(double);
     hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(kEpiThreads), epi_lds, s, g, io);
