@@ -298,3 +298,35 @@ def test_mfma_folded_head_with_an_injected_state(G):
     for n in (4096, 8192 + 5, 4096, 20000):
         step(n)
     gb.close()
+
+
+@pytest.mark.parametrize("taps", [2, 3, 9, 17, 128, 129, 130, 257, 300, 513])
+def test_end_state_kernels_at_their_boundary(G, taps):
+    """The tap-aligned end-state kernel serves blocks with at least K samples (K-1 regular ones even when
+    stable_init took the first), the sample-aligned one the shorter blocks: block lengths around K, chain counts
+    around a pass (128 chains) and a 16-tap block, both initialisers, both modes; the carried delay line to the bit
+    after every block, outputs to the mode's bar."""
+    from dsp_amd import bank as gbank
+    rng = np.random.default_rng(9000 + taps)
+    b = rng.standard_normal(taps) / taps ** 0.5
+    for partial in (False, True):
+        for mode in (gbank.MODE_AUTO, gbank.MODE_SEQUENTIAL):
+            d = gbank.fir_design(b, partial=partial)
+            small = gbank.fir_design(b[: max(1, taps // 3)], partial=partial)      # a shorter filter in the same group
+            blocks = [max(1, taps - 1), taps, taps + 1, taps + 5, 2 * taps, 4096 + taps, 1]
+            ys_g, ys_o, gb, ob = G.run_pair([d, small], [0, 1, 0], blocks[:1], mode, seed=taps)
+            pos = blocks[0]
+            for n in blocks[1:]:
+                x = G.make_inputs(taps, 3, n, pos)
+                pos += n
+                yg, yo = gb(G.to_dev(x)).cpu().numpy(), ob.updaten(x, threads=2)
+                if mode == gbank.MODE_SEQUENTIAL:
+                    assert util.bits_equal(yg, yo), (taps, partial, n)
+                else:
+                    assert float(np.max(util.rel_to_peak(yg, yo))) <= TOL_MFMA, (taps, partial, n)
+                st, fv, ini = gb.get_state()
+                assert util.bits_equal(st[:, :ob.state.shape[1]], ob.state), (taps, partial, mode, n)
+                assert np.array_equal(ini, ob.init), (taps, partial, mode, n)
+                if mode == gbank.MODE_SEQUENTIAL:                       # filtered_value is the last output
+                    assert util.bits_equal(fv, ob.fval), (taps, partial, n)
+            gb.close()
