@@ -51,7 +51,7 @@ def main():
     steady = pick(s3["pmc_mfma"], "fir_mfma_kernel<")[0]
     hbm3 = int(tot_f * 1024 * 2 + tot_w * 1024)
     alg3 = 65536 * 65536 * 16
-    json.dump({"kernels": "fir_prologue + fir_mfma_edge + fir_mfma_kernel<true> + fir_epilogue (one step of config 3)",
+    json.dump({"kernels": "fir_prologue + fir_mfma_kernel<true> (head included) + fir_epilogue_taps (one step of config 3)",
                "source": "profiles/" + RND + "_config3_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
                          "bench.py --workload fir512 --steps 3 --warmup 1 --no-cpu)",
                "FETCH_SIZE_KiB_per_step": tot_f, "WRITE_SIZE_KiB_per_step": tot_w, "correction": CORR,
