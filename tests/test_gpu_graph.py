@@ -54,3 +54,49 @@ def test_block_updates_replayed_from_a_graph(G, case):
         assert util.bits_equal(got, want)
     else:
         assert np.all(util.rel_to_peak(got, want) <= 1e-12)
+
+
+@pytest.mark.parametrize("case", ["iir-scan", "fir-mfma", "fir-exact"])
+def test_a_graph_of_two_calls_replayed_twice_continues_the_streams(G, case):
+    """Replaying the same graph again feeds the same input blocks to the running streams: IIR state is updated in
+    place, the time-split FIR kernels alternate two state buffers per call (so an EVEN number of captured calls
+    lands where it started: include/RTFilterBank.h)."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    if case == "iir-scan":
+        designs, mode = [G.golden_design("bw4_bp_0.3_0.6")], gbank.MODE_SCAN
+    else:
+        designs = [G.golden_design("fir32_lp_0.25")]
+        mode = gbank.MODE_SEQUENTIAL if case == "fir-exact" else gbank.MODE_AUTO
+    nch, n = 40, 8192
+    gb = gbank.FilterBank(designs, [0] * nch, mode=mode)
+    ob = orc.Bank([G.to_orc_design(d) for d in designs], [0] * nch)
+    x = G.make_inputs(23, nch, 3 * n)
+    xd = G.to_dev(x)
+    yd = torch.zeros_like(xd)
+    ld = 3 * n
+    gb.updaten_ptr(yd.data_ptr(), ld, xd.data_ptr(), ld, n)            # block 0 outside the graph (stable_init)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        for j in (1, 2):
+            gb.updaten_ptr(yd.data_ptr() + j * n * 8, ld, xd.data_ptr() + j * n * 8, ld, n, torch.cuda.current_stream())
+    ob.updaten(x[:, :n].copy(), threads=4)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ob.updaten(x[:, n:].copy(), threads=4)                  # the same two blocks again, stream running on
+        got = yd[:, n:].cpu().numpy()
+        if case == "fir-exact":
+            assert util.bits_equal(got, want)
+        else:
+            assert np.all(util.rel_to_peak(got, want) <= 1e-12)
+    st, fv, ini = gb.get_state()
+    w = ob.state.shape[1]
+    if case == "iir-scan":
+        assert np.max(np.abs(st[:, :w] - ob.state)) <= 1e-12 * max(1.0, float(np.max(np.abs(ob.state))))
+    else:
+        assert util.bits_equal(st[:, :w], ob.state)
+    gb.close()
