@@ -574,7 +574,7 @@ def main_mixed(args):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config 4: %d-channel mixed bank (%s) x 64K samples, channel-sharded, waves of %d "
-                                   "channels" % (total, "2^19 IIR order 8 + 2^19 FIR 32 taps, sorted by type"
+                                   "channels" % (total, "%d IIR order 8 + %d FIR 32 taps, sorted by type" % (total // 2, total - total // 2)
                                                  if args.mixed_layout == "sorted" else
                                                  "IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved", wave),
                        "channels_per_gpu": per_rank, "wave_channels": wave, "waves_per_gpu": nwaves, "block": BLOCK,
