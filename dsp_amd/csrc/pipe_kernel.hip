@@ -555,8 +555,46 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     }
 }
 
+/* workgroups of the pipelined kernel the device holds at once (4 per CU: two 16 KiB tiles each, 2 waves per SIMD) */
+static int pipe_resident_round()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return 4 * cus;
+}
+
+template <int N>
+static hipError_t launch_pipe_one(const GroupView &g, const BlockIO &io, hipStream_t s);
+
+/* Groups a little wider than one resident round are launched round by round: a launch of 1.25 .. 4 rounds runs its
+ * later workgroups against the drain of the first round and loses 1-5 % against the same channels as back-to-back
+ * launches of one round each (2048 channels x 64K: 464 -> 438 us, profiles/r2_split_launch.txt); from ~6 rounds on
+ * the single launch wins. */
 template <int N>
 static hipError_t launch_pipe_n(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    const int round = pipe_resident_round();
+    if (g.count <= round || g.count > 4 * round) return launch_pipe_one<N>(g, io, s);
+    for (int off = 0; off < g.count; off += round) {
+        GroupView h = g;
+        h.chan = g.chan ? g.chan + off : nullptr;
+        h.chan0 = g.chan0 + off;
+        h.count = g.count - off < round ? g.count - off : round;
+        h.design = g.design + off;
+        h.state = g.state + (size_t)off * g.state_ld;
+        h.fval = g.fval + off;
+        h.init = g.init + off;
+        if (g.aux) h.aux = g.aux + (size_t)off * 64;         /* diagnostics: 32 stamps per workgroup */
+        const hipError_t e = launch_pipe_one<N>(h, io, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <int N>
+static hipError_t launch_pipe_one(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
     const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * (N + 2);
     const bool whole = io.aligned16 && io.n % kPSeg == 0;

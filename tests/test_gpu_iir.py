@@ -308,3 +308,33 @@ def test_many_distinct_designs_take_the_scan2_kernel(G):
             else:
                 assert np.max(np.abs(y[c] - yo)) / np.max(np.abs(yo)) <= 1e-12, c
         gb.close()
+
+
+def test_groups_a_little_wider_than_a_resident_round_are_launched_round_by_round():
+    """1024 < channels <= 4096 on the pipelined kernel: the launcher walks the group in resident rounds (offsets into
+    the per-channel arrays, contiguous and listed channels).  Two designs interleaved unevenly so that one group is a
+    channel LIST of 1300 entries and the other a list of 1200; against the bit-exact kernel on every channel and the
+    oracle on a few; state carried over a second, ragged block."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    from tests import gpu_util as G
+    d8 = G.golden_design("bw4_bp_0.3_0.6")
+    d5 = G.golden_design("bw5_lp_0.25")
+    nch = 2500
+    idx = [0 if (c % 25) < 13 else 1 for c in range(nch)]
+    x = G.make_inputs(41, nch, 8192 + 4096 + 77)
+    outs = {}
+    for name, mode in (("auto", gbank.MODE_AUTO), ("seq", gbank.MODE_SEQUENTIAL)):
+        gb = gbank.FilterBank([d8, d5], idx, mode=mode)
+        ys = [gb(G.to_dev(x[:, :8192])).cpu().numpy(), gb(G.to_dev(x[:, 8192:])).cpu().numpy()]
+        outs[name] = (np.concatenate(ys, axis=1), gb.get_state())
+        gb.close()
+    err = util.rel_to_peak(outs["auto"][0], outs["seq"][0])
+    assert float(np.max(err)) <= 1e-12
+    st_a, st_s = outs["auto"][1][0], outs["seq"][1][0]
+    assert np.max(np.abs(st_a - st_s)) <= 1e-12 * max(1.0, float(np.max(np.abs(st_s))))
+    for c in (0, 13, 1299, 1300, 2499):
+        ob = orc.Bank([G.to_orc_design(d8), G.to_orc_design(d5)], [idx[c]])
+        want = ob.updaten(x[c:c + 1], threads=1)
+        assert util.bits_equal(outs["seq"][0][c:c + 1], want)
