@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsp_amd import bank as gbank
 from tests import util
-_, b, a = util.design_coefs("bw4_bp_0.3_0.6")
+_, b, a = util.design_coefs(sys.argv[1] if len(sys.argv) > 1 else "bw4_bp_0.3_0.6")     # e.g. bw8_bp_0.25_0.75: order 16
 s = torch.cuda.current_stream()
 N, RING = 65536, 4
 d = gbank.iir_design(b, a)
