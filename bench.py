@@ -141,9 +141,13 @@ def main():
     ap.add_argument("--gather-fval", action="store_true",
                     help="config 4: all_gather one double per channel (the last output) after each block instead")
     ap.add_argument("--fir-channels", type=int, default=65536)
-    ap.add_argument("--layout", choices=["blocks", "rows"], default="blocks",
+    ap.add_argument("--layout", choices=["tiles", "blocks", "rows"], default="tiles",
                     help="config 2: how the resident 2^20-sample streams lie in HBM: `rows` = one row of 2^20 samples per "
-                         "channel, `blocks` = 16 block buffers of 1024 x 64K")
+                         "channel, `blocks` = 16 block buffers of 1024 x 64K (dense rows), `tiles` = 16 block buffers in the "
+                         "tiled block layout [32][1024][2048] (RTFilterBank_updaten_tiled)")
+    ap.add_argument("--chained", action="store_true",
+                    help="config 2: hand the blocks over with RTFilterBank_updaten_chained (block k+1 overlaps the drain "
+                         "of block k on the bank's internal streams) instead of in stream order")
     ap.add_argument("--block-pad", type=int, default=0, help="layout blocks: extra doubles per row")
     ap.add_argument("--settle-ms", type=float, default=60.0,
                     help="untimed: keep the GPU busy with the hot path for this long BEFORE the warm-up steps, so "
@@ -183,7 +187,20 @@ def main():
     else:
         bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
 
-    if args.layout == "rows":
+    tiled = args.layout == "tiles"
+    if tiled:
+        # the stream as it is streamed, every 64K block in the tiled block layout [32 segments][1024 channels][2048]
+        pitch = gbank.TILE
+        xbuf = torch.empty((NBLOCKS, BLOCK // gbank.TILE, CHANNELS, gbank.TILE), dtype=torch.float64, device=dev)
+        ybuf = torch.empty_like(xbuf)
+        rows_tmp = torch.empty((CHANNELS, BLOCK), dtype=torch.float64, device=dev)
+        for j in range(NBLOCKS):
+            gbank.synth_fill(rows_tmp, SEED, chan0=rank * CHANNELS, n0=j * BLOCK)
+            gbank.tile_rows(rows_tmp, xbuf[j])
+        del rows_tmp
+        xptr = [xbuf[j].data_ptr() for j in range(NBLOCKS)]
+        yptr = [ybuf[j].data_ptr() for j in range(NBLOCKS)]
+    elif args.layout == "rows":
         # every channel's 2^20 samples contiguous (row pitch 2^20 + 128 doubles); block j = columns [j*64K, (j+1)*64K)
         pitch = PITCH
         xbuf = torch.empty((CHANNELS, PITCH), dtype=torch.float64, device=dev)
@@ -211,11 +228,33 @@ def main():
             bank.reset(stream)
         if ev is not None:
             ev[0].record(stream)
-        bank.updaten_ptr(yptr[j], pitch, xptr[j], pitch, BLOCK, stream)
+        if args.chained:
+            bank.updaten_chained_ptr(yptr[j], pitch, xptr[j], pitch, BLOCK, tiled=tiled, stream=stream)
+            if ev is not None:
+                bank.chain_join(stream)
+        elif tiled:
+            bank.updaten_tiled_ptr(yptr[j], xptr[j], BLOCK, stream)
+        else:
+            bank.updaten_ptr(yptr[j], pitch, xptr[j], pitch, BLOCK, stream)
         if ev is not None:
             ev[1].record(stream)
         step_no[0] += 1
 
+    # untimed extra, first thing after an idle pause: the same K steps from cold clocks (no settle pass, no warm-up)
+    cold_value = None
+    if args.settle_ms > 0:
+        time.sleep(0.25)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(stream)
+        for _ in range(args.steps):
+            step()
+        if args.chained:
+            bank.chain_join(stream)
+        c1.record(stream)
+        torch.cuda.synchronize()
+        cold_value = CHANNELS * BLOCK * args.steps / (c0.elapsed_time(c1) / 1e3) / 1e6
+        step_no[0] = 0
+        bank.reset(stream)
     # untimed, before the warm-up: bring the device out of its idle clocks (profiles/r2_rampup.txt)
     settle_steps = 0
     t_settle = time.perf_counter()
@@ -241,6 +280,8 @@ def main():
     e_begin.record(stream)
     for k in range(args.steps):
         step()
+    if args.chained:
+        bank.chain_join(stream)              # `stream` waits for the last link: inside the timed region
     e_end.record(stream)
     torch.cuda.synchronize()
     if dist is not None:
@@ -271,14 +312,57 @@ def main():
             j = k % NBLOCKS
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            rc = dspdll.dsp_copy_rows(C.c_void_p(yptr[j]), pitch, C.c_void_p(xptr[j]), pitch, CHANNELS, BLOCK,
-                                      256, 8192, C.c_void_p(stream.cuda_stream))
+            if tiled:
+                rc = dspdll.dsp_copy_tiles(C.c_void_p(yptr[j]), C.c_void_p(xptr[j]), CHANNELS, BLOCK,
+                                           C.c_void_p(stream.cuda_stream))
+            else:
+                rc = dspdll.dsp_copy_rows(C.c_void_p(yptr[j]), pitch, C.c_void_p(xptr[j]), pitch, CHANNELS, BLOCK,
+                                          256, 8192, C.c_void_p(stream.cuda_stream))
             e1.record(stream)
             torch.cuda.synchronize()
             if rc == 0 and k >= 4:
                 cts.append(e0.elapsed_time(e1))
         if cts:
             copy_gbs = CHANNELS * BLOCK * BYTES_PER_SAMPLE / (float(np.median(cts)) / 1e3) / 1e9
+
+    # untimed extra, rank 0: the other ways the same blocks can be handed over (same bank design, fresh banks)
+    others = {}
+    if rank == 0 and not args.jitter:
+        def leg(layout_tiled, chained):
+            bk = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
+            if layout_tiled == tiled:
+                xs, ys, p = xptr, yptr, pitch
+            else:                             # four block buffers in the other layout (re-used by the 16 blocks)
+                shape = (4, BLOCK // gbank.TILE, CHANNELS, gbank.TILE) if layout_tiled else (4, CHANNELS, BLOCK)
+                xo = torch.empty(shape, dtype=torch.float64, device=dev).normal_()
+                yo = torch.empty_like(xo)
+                xs = [xo[j % 4].data_ptr() for j in range(NBLOCKS)]
+                ys = [yo[j % 4].data_ptr() for j in range(NBLOCKS)]
+                p = gbank.TILE if layout_tiled else BLOCK
+            t0e, t1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for timed in (False, True):
+                if timed:
+                    t0e.record(stream)
+                for k in range(32):
+                    j = k % NBLOCKS
+                    if chained:
+                        bk.updaten_chained_ptr(ys[j], p, xs[j], p, BLOCK, tiled=layout_tiled, stream=stream)
+                    elif layout_tiled:
+                        bk.updaten_tiled_ptr(ys[j], xs[j], BLOCK, stream)
+                    else:
+                        bk.updaten_ptr(ys[j], p, xs[j], p, BLOCK, stream)
+                if chained:
+                    bk.chain_join(stream)
+            t1e.record(stream)
+            torch.cuda.synchronize()
+            bk.close()
+            return CHANNELS * BLOCK * 32 / (t0e.elapsed_time(t1e) / 1e3) / 1e6
+        for name, lt, ch in (("dense rows (RTFilterBank_updaten), stream order", False, False),
+                             ("dense rows, RTFilterBank_updaten_chained", False, True),
+                             ("tiles (RTFilterBank_updaten_tiled), stream order", True, False),
+                             ("tiles, RTFilterBank_updaten_chained", True, True)):
+            if (lt, ch) != (tiled, args.chained):
+                others[name] = leg(lt, ch)
 
     if rank == 0:
         samples_per_step = CHANNELS * BLOCK
@@ -293,7 +377,10 @@ def main():
                                    "(butterworth(4,0.3,0.6)), 2^20 samples/channel resident, "
                                    "64K-sample blocks, state carried in HBM",
                        "channels_per_gpu": CHANNELS, "block": BLOCK, "stream": STREAM,
-                       "layout": args.layout, "row_pitch_doubles": pitch, "settle_steps_untimed": settle_steps,
+                       "layout": args.layout + (": every 64K block stored [32 segments][1024 channels][2048 samples], "
+                                                "RTFilterBank_updaten_tiled" if tiled else ""),
+                       "hand_over": "RTFilterBank_updaten_chained" if args.chained else "stream order",
+                       "row_pitch_doubles": pitch, "settle_steps_untimed": settle_steps,
                        "distinct_designs": CHANNELS if args.jitter else 1,
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -305,6 +392,8 @@ def main():
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "kernel_ms_avg": kern_avg_s * 1e3,
                          "single_launch_ms_avg": float(np.mean(kern_ms)), "single_launch_ms_min": float(np.min(kern_ms))},
+            "cold_start_msamples_s": cold_value,
+            "other_hand_overs_msamples_s": others,
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(b, a)

@@ -170,6 +170,26 @@ class FilterBank:
         _check(dspdll.RTFilterBank_updaten_noalloc(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr),
                                                    ld_in, n, _stream_ptr(stream, self.device)), "RTFilterBank_updaten_noalloc")
 
+    def updaten_tiled_ptr(self, out_ptr, in_ptr, n, stream=None):
+        """RTFilterBank_updaten_tiled: in / out are [n / TILE][nch][TILE] device blocks."""
+        _check(dspdll.RTFilterBank_updaten_tiled(self._handle, C.c_void_p(out_ptr), C.c_void_p(in_ptr), n,
+                                                 _stream_ptr(stream, self.device)), "RTFilterBank_updaten_tiled")
+
+    def updaten_chained_ptr(self, out_ptr, ld_out, in_ptr, ld_in, n, tiled=False, stream=None, want_event=False):
+        """RTFilterBank_updaten_chained: block k+1 overlaps the drain of block k on the bank's internal streams.
+        Returns the block's done event (a raw hipEvent_t as int) when want_event, else None."""
+        ev = C.c_void_p()
+        _check(dspdll.RTFilterBank_updaten_chained(self._handle, C.c_void_p(out_ptr), ld_out, C.c_void_p(in_ptr), ld_in,
+                                                   n, cdsp.RTFB_CHAIN_TILED if tiled else 0,
+                                                   _stream_ptr(stream, self.device),
+                                                   C.byref(ev) if want_event else None),
+               "RTFilterBank_updaten_chained")
+        return ev.value if want_event else None
+
+    def chain_join(self, stream=None):
+        """`stream` waits for every chained call so far; the carried state is back in place."""
+        _check(dspdll.RTFilterBank_chain_join(self._handle, _stream_ptr(stream, self.device)), "RTFilterBank_chain_join")
+
     def filter_host(self, x, out=None):
         """x: (nch, n) float64 numpy array in host memory (rows contiguous): RTFilterBank_updaten_host, the
         reference's per-filter call on host arrays, staged through pinned rings.  Returns `out`."""
@@ -230,6 +250,35 @@ class FilterBank:
                                              ptr(fval, np.float64, C.c_double),
                                              ptr(init, np.int32, C.c_int32), _stream_ptr(stream, self.device)),
                "RTFilterBank_set_state")
+
+
+TILE = cdsp.RTFB_TILE
+
+
+def tile_rows(rows, tiles=None, stream=None):
+    """(nch, n) device tensor (row stride free) -> the tiled block layout [n / TILE][nch][TILE]."""
+    import torch
+    nch, n = rows.shape
+    assert n % TILE == 0 and rows.dtype == torch.float64 and (rows.stride(1) == 1 or n <= 1)
+    if tiles is None:
+        tiles = torch.empty((n // TILE, nch, TILE), dtype=torch.float64, device=rows.device)
+    assert tiles.is_contiguous() and tiles.numel() == nch * n
+    _check(dspdll.dsp_tile_rows(C.c_void_p(tiles.data_ptr()), C.c_void_p(rows.data_ptr()), rows.stride(0), nch, n,
+                                _stream_ptr(stream, rows.device)), "dsp_tile_rows")
+    return tiles
+
+
+def untile_rows(tiles, rows=None, stream=None):
+    """[n / TILE][nch][TILE] -> (nch, n)."""
+    import torch
+    nseg, nch, t = tiles.shape
+    assert t == TILE and tiles.is_contiguous() and tiles.dtype == torch.float64
+    if rows is None:
+        rows = torch.empty((nch, nseg * TILE), dtype=torch.float64, device=tiles.device)
+    assert rows.shape == (nch, nseg * TILE) and rows.stride(1) == 1
+    _check(dspdll.dsp_untile_rows(C.c_void_p(rows.data_ptr()), rows.stride(0), C.c_void_p(tiles.data_ptr()), nch,
+                                  nseg * TILE, _stream_ptr(stream, tiles.device)), "dsp_untile_rows")
+    return rows
 
 
 def synth_fill(tensor, seed, chan0=0, n0=0, stream=None):

@@ -173,6 +173,13 @@ _proto("RTFilterBank_updaten", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c
 _proto("RTFilterBank_updaten_noalloc", c_int,
        [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterBank_noalloc_max_doubles", c_size_t, [])
+RTFB_TILE, RTFB_CHAIN_TILED = 2048, 1
+_proto("RTFilterBank_updaten_tiled", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p])
+_proto("RTFilterBank_updaten_chained", c_int,
+       [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_uint, c_void_p, POINTER(c_void_p)])
+_proto("RTFilterBank_chain_join", c_int, [c_void_p, c_void_p])
+_proto("dsp_tile_rows", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
+_proto("dsp_untile_rows", c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterBank_updaten_host", c_int, [c_void_p, _dp, c_size_t, _dp, c_size_t, c_size_t])
 _proto("RTFilterBankFeed_create", c_int, [POINTER(c_void_p), c_void_p, c_size_t])
 _proto("RTFilterBankFeed_destroy", None, [c_void_p])
@@ -196,6 +203,7 @@ _proto("dsp_pool_bytes_in_use", c_size_t, [c_int])
 _proto("dsp_pool_bytes_cached", c_size_t, [c_int])
 _proto("dsp_synth_fill", c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_uint64, c_uint64, c_uint64, c_void_p])
 _proto("dsp_copy_rows", c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_int, c_void_p])
+_proto("dsp_copy_tiles", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p])
 _proto("dsp_device_count", c_int, [])
 _proto("dsp_memcpy_h2d", c_int, [c_void_p, c_void_p, c_size_t, c_int])
 _proto("dsp_memcpy_d2h", c_int, [c_void_p, c_void_p, c_size_t, c_int])

@@ -464,9 +464,31 @@ struct Group {
     bool contiguous = false;
 };
 
+/* RTFilterBank_updaten_chained: two internal streams, a ring of events and the device words of ChainView
+ * (dsp_internal.h).  Built by the first chained call of a bank, released with the bank. */
+constexpr int kChainRing = 4;
+struct ChainState {
+    bool ready = false;                 /* device words below exist                                           */
+    bool have_events = false;           /* streams, events and the pinned error word exist                    */
+    bool open = false;                  /* links are in flight: the group's plain state arrays are stale       */
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t done[kChainRing] = {}, in_ready[kChainRing] = {};
+    uint64_t seq = 0;                   /* chained launches of this bank so far; generation of the next = seq + 1 */
+    uint64_t links = 0;                 /* launches of the chain that is open                                  */
+    int count = 0, order = 0;
+    unsigned long long *d_queue = nullptr;      /* kChainRing x count ready-queue entries                     */
+    unsigned long long *d_counters = nullptr;   /* finished[slot] at 16 * slot, started[slot] at 16 * (ring + slot): a
+                                                   128-byte line each                                          */
+    unsigned int *d_error = nullptr;
+    unsigned int *h_error = nullptr;            /* pinned: the error word as of the last join                  */
+    double *d_records = nullptr;
+    unsigned long long finished_total[kChainRing] = {}, started_total[kChainRing] = {};
+};
+
 }  // namespace
 
 struct RTFilterBank {
+    ChainState chain;
     int device = 0;
     size_t nch = 0;
     int mode = RTFB_MODE_AUTO;
@@ -1118,6 +1140,125 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     return v;
 }
 
+/* ---- chained block updates (RTFilterBank_updaten_chained) ---------------------------------------------------- */
+
+void chain_release(RTFilterBank *bk)
+{
+    ChainState &c = bk->chain;
+    for (int k = 0; k < 2; ++k)
+        if (c.s[k]) {
+            (void)hipStreamSynchronize(c.s[k]);
+            (void)hipStreamDestroy(c.s[k]);
+        }
+    for (int k = 0; k < kChainRing; ++k) {
+        if (c.done[k]) (void)hipEventDestroy(c.done[k]);
+        if (c.in_ready[k]) (void)hipEventDestroy(c.in_ready[k]);
+    }
+    pool_free(c.d_queue);
+    pool_free(c.d_counters);
+    pool_free(c.d_error);
+    pool_free(c.d_records);
+    if (c.h_error) (void)hipHostFree(c.h_error);
+    c = ChainState();
+}
+
+/* The one launch group a chain can run on, or nullptr: a single group of orders <= 8 that the pipelined kernel
+ * serves (tables present, design admitted by the probe or RTFB_MODE_SCAN), no wider than one resident round. */
+Group *chain_group(RTFilterBank *bk)
+{
+    if (bk->groups.size() != 1) return nullptr;
+    Group &g = bk->groups[0];
+    if (g.cls != kIirFast || g.stage != 0 || g.order < 1 || g.order > kScan2MaxOrder || !g.has_tables) return nullptr;
+    if (bk->designs.size() > kMaxPipeDesigns) return nullptr;
+    if (bk->mode == RTFB_MODE_SEQUENTIAL || (bk->mode == RTFB_MODE_AUTO && !g.scan_safe)) return nullptr;
+    return &g;
+}
+
+/* streams, events, pinned error word (also what a call that falls back to stream order hands out as done_event) */
+int chain_prepare_events(RTFilterBank *bk)
+{
+    ChainState &c = bk->chain;
+    if (c.have_events) return RTFB_OK;
+    int rc = RTFB_OK;
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail_hip(e, what);
+        return e == hipSuccess;
+    };
+    for (int k = 0; k < 2 && !rc; ++k) hipok(hipStreamCreateWithFlags(&c.s[k], hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < kChainRing && !rc; ++k)
+        hipok(hipEventCreateWithFlags(&c.done[k], hipEventDisableTiming), "hipEventCreate") &&
+            hipok(hipEventCreateWithFlags(&c.in_ready[k], hipEventDisableTiming), "hipEventCreate");
+    if (!rc) hipok(hipHostMalloc(reinterpret_cast<void **>(&c.h_error), 64, hipHostMallocDefault), "hipHostMalloc");
+    if (rc) {
+        const std::string keep = t_last_error;
+        chain_release(bk);
+        t_last_error = keep;
+        return rc;
+    }
+    *c.h_error = 0;
+    c.have_events = true;
+    return RTFB_OK;
+}
+
+int chain_prepare(RTFilterBank *bk, const Group &g)
+{
+    ChainState &c = bk->chain;
+    if (c.ready) return RTFB_OK;
+    int rc = chain_prepare_events(bk);
+    if (rc) return rc;
+    const int device = bk->device;
+    const size_t cnt = g.chans.size();
+    auto hipok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && !rc) rc = fail_hip(e, what);
+        return e == hipSuccess;
+    };
+    void *p = nullptr;
+    const size_t qbytes = (size_t)kChainRing * cnt * sizeof(unsigned long long);
+    const size_t cbytes = (size_t)2 * kChainRing * 16 * sizeof(unsigned long long);
+    const size_t rbytes = cnt * (size_t)(2 * (g.order + 2)) * sizeof(double);
+    if (!rc && !(rc = pool_alloc(&p, qbytes, device))) c.d_queue = static_cast<unsigned long long *>(p);
+    if (!rc && !(rc = pool_alloc(&p, cbytes, device))) c.d_counters = static_cast<unsigned long long *>(p);
+    if (!rc && !(rc = pool_alloc(&p, 256, device))) c.d_error = static_cast<unsigned int *>(p);
+    if (!rc && !(rc = pool_alloc(&p, rbytes, device))) c.d_records = static_cast<double *>(p);
+    if (!rc) {
+        hipok(hipMemset(c.d_queue, 0, qbytes), "hipMemset") && hipok(hipMemset(c.d_counters, 0, cbytes), "hipMemset") &&
+            hipok(hipMemset(c.d_error, 0, 256), "hipMemset") && hipok(hipMemset(c.d_records, 0, rbytes), "hipMemset") &&
+            hipok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    if (rc) {
+        const std::string keep = t_last_error;
+        chain_release(bk);
+        t_last_error = keep;
+        return rc;
+    }
+    c.count = (int)cnt;
+    c.order = g.order;
+    c.ready = true;
+    return RTFB_OK;
+}
+
+/* End the open chain: `s` waits for every link, the carry records go back into the group's plain arrays, the
+ * error word is copied to the host.  Enqueues only.  Every other entry point of the bank calls this first. */
+int chain_close(RTFilterBank *bk, hipStream_t s)
+{
+    ChainState &c = bk->chain;
+    if (c.h_error && *c.h_error)
+        return fail(RTFB_EDEVICE, "RTFilterBank_updaten_chained: a bounded wait between chained launches ran out (code " +
+                                      std::to_string(*c.h_error) + "); the bank's state is undefined, rebuild it");
+    if (!c.open) return RTFB_OK;
+    DeviceScope ds(bk->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    const uint64_t last = c.seq - 1;
+    HIP_TRY(hipStreamWaitEvent(s, c.done[last % kChainRing], 0));
+    if (c.links >= 2) HIP_TRY(hipStreamWaitEvent(s, c.done[(last - 1) % kChainRing], 0));
+    Group &g = bk->groups[0];
+    HIP_TRY(launch_chain_unpack(c.d_records, g.d_state, g.d_fval, g.d_init, c.count, c.order, g.state_ld, s));
+    HIP_TRY(hipMemcpyAsync(c.h_error, c.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    c.open = false;
+    c.links = 0;
+    return RTFB_OK;
+}
+
 int validate_design(const RTFilterDesign &d)
 {
     if (d.kind != RTFB_KIND_IIR && d.kind != RTFB_KIND_FIR && d.kind != RTFB_KIND_FIR_PARTIAL &&
@@ -1477,6 +1618,7 @@ void RTFilterBank_destroy(RTFilterBank *bank)
         (void)hipDeviceSynchronize();
     }
     host_pipe_release(bank->host);
+    chain_release(bank);
     free_bank_device(bank);
     delete bank;
 }
@@ -1513,6 +1655,22 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
     io.aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) &&
                    ld_in % 2 == 0 && ld_out % 2 == 0;
 
+    {
+        int rc = chain_close(bank, s);
+        if (rc) return rc;
+    }
+    const double *in_end = in + (bank->nch - 1) * ld_in + n;
+    const double *out_end = out + (bank->nch - 1) * ld_out + n;
+    const bool overlap = in < out_end && out < in_end;
+    if (no_alloc && overlap && bank->nch * n > kStaticScratchDoubles) {
+        /* refused BEFORE anything is enqueued: groups launched ahead of the FIR group would already have
+         * advanced their channels */
+        for (const Group &g : bank->groups)
+            if (g.cls == kFir)
+                return fail(RTFB_ESIZE, "RTFilterBank_updaten_noalloc: an in-place call on FIR channels stages "
+                                        "channels x n doubles; the static scratch holds " +
+                                            std::to_string(kStaticScratchDoubles));
+    }
     const BlockIO io_first = io;
     for (Group &g : bank->groups) {
         GroupView v = view_of(bank, g);
@@ -1527,20 +1685,13 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
              * own outputs as inputs: an in-place call (allowed by the reference, where each
              * sample is read before its slot is written) reads from a private copy instead. */
             BlockIO fio = io;
-            const double *in_end = in + (bank->nch - 1) * ld_in + n;
-            const double *out_end = out + (bank->nch - 1) * ld_out + n;
-            if (in < out_end && out < in_end && no_alloc) {
-                /* staging through this GPU's static array: no pool, no hipMalloc */
-                const size_t need = bank->nch * n;
-                if (need > kStaticScratchDoubles)
-                    return fail(RTFB_ESIZE, "RTFilterBank_updaten_noalloc: an in-place call on FIR channels stages "
-                                            "channels x n doubles; the static scratch holds " +
-                                                std::to_string(kStaticScratchDoubles));
+            if (overlap && no_alloc) {
+                /* staging through this GPU's static array: no pool, no hipMalloc (size checked above) */
                 HIP_TRY(hipMemcpy2DAsync(bank->d_static_scratch, n * sizeof(double), in, ld_in * sizeof(double),
                                          n * sizeof(double), bank->nch, hipMemcpyDeviceToDevice, s));
                 fio.in = bank->d_static_scratch;
                 fio.ld_in = n;
-            } else if (in < out_end && out < in_end) {
+            } else if (overlap) {
                 const size_t need = bank->nch * n;
                 if (g.scratch_doubles < need) {
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1603,6 +1754,154 @@ int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out,
 
 size_t RTFilterBank_noalloc_max_doubles(void) { return kStaticScratchDoubles; }
 
+/* Shared by _updaten_tiled and _updaten_chained: argument checks, the block's addressing.  tiled: in / out are
+ * [n / 2048][nch][2048] (ld ignored). */
+static int pipe_block(const RTFilterBank *bank, double *out, size_t ld_out, const double *in, size_t ld_in, size_t n,
+                      bool tiled, BlockIO *io, PipeExt *ext)
+{
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16) != 0)
+        return fail(RTFB_EINVAL, "in / out must be 16-byte aligned");
+    if (n % RTFB_TILE) return fail(RTFB_ESIZE, "n must be a multiple of RTFB_TILE (2048) samples");
+    io->out = out;
+    io->in = in;
+    io->n = n;
+    io->aligned16 = 1;
+    *ext = PipeExt();
+    if (tiled) {
+        io->ld_in = io->ld_out = RTFB_TILE;
+        ext->seg_in = ext->seg_out = bank->nch * (size_t)RTFB_TILE;
+    } else {
+        if (bank->nch > 1 && (ld_in < n || ld_out < n)) return fail(RTFB_EINVAL, "ld smaller than n");
+        if (ld_in % 2 || ld_out % 2) return fail(RTFB_EINVAL, "row pitches must be even (16-byte aligned rows)");
+        io->ld_in = ld_in;
+        io->ld_out = ld_out;
+        ext->seg_in = ext->seg_out = RTFB_TILE;
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream)
+{
+    if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten_tiled: NULL argument");
+    if (n == 0) return RTFB_OK;
+    Group *g = chain_group(bank);
+    if (!g)
+        return fail(RTFB_EUNSUPPORTED, "the tiled block layout is served by the pipelined IIR kernel only: one launch "
+                                       "group of order <= 8, <= 1024 designs, scan-safe (or RTFB_MODE_SCAN)");
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    BlockIO io;
+    PipeExt ext;
+    int rc = pipe_block(bank, out, 0, in, 0, n, true, &io, &ext);
+    if (rc || (rc = chain_close(bank, s))) return rc;
+    const GroupView v = view_of(bank, *g);
+    const int round = pipe_resident_round();
+    /* a group a little wider than one resident round goes round by round, as in launch_pipe_n */
+    const int step = (v.count > round && v.count <= 4 * round) ? round : v.count;
+    for (int off = 0; off < v.count; off += step) {
+        GroupView h = v;
+        h.chan = v.chan ? v.chan + off : nullptr;
+        h.chan0 = v.chan0 + off;
+        h.count = std::min(step, v.count - off);
+        h.design = v.design + off;
+        h.state = v.state + (size_t)off * v.state_ld;
+        h.fval = v.fval + off;
+        h.init = v.init + off;
+        HIP_TRY(launch_iir_pipe_ext(g->order, h, io, ext, s));
+    }
+    return RTFB_OK;
+}
+
+int RTFilterBank_updaten_chained(RTFilterBank *bank, double *out, size_t ld_out, const double *in, size_t ld_in,
+                                 size_t n, unsigned flags, void *hip_stream, void **done_event)
+{
+    if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten_chained: NULL argument");
+    if (flags & ~(unsigned)RTFB_CHAIN_TILED) return fail(RTFB_EINVAL, "RTFilterBank_updaten_chained: unknown flag");
+    if (done_event) *done_event = nullptr;
+    if (n == 0) return RTFB_OK;
+    const bool tiled = (flags & RTFB_CHAIN_TILED) != 0;
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    Group *g = chain_group(bank);
+    const bool chainable = g && (int)g->chans.size() <= pipe_resident_round() && n % RTFB_TILE == 0 &&
+                           ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16) == 0 &&
+                           (tiled || (ld_in % 2 == 0 && ld_out % 2 == 0));
+    if (!chainable) {
+        /* stream order: the same results, no overlap with the call before */
+        int rc = tiled ? RTFilterBank_updaten_tiled(bank, out, in, n, hip_stream)
+                       : RTFilterBank_updaten(bank, out, ld_out, in, ld_in, n, hip_stream);
+        if (rc || !done_event) return rc;
+        if ((rc = chain_prepare_events(bank))) return rc;
+        ChainState &c = bank->chain;
+        hipEvent_t ev = c.done[c.seq % kChainRing];
+        c.seq++;
+        HIP_TRY(hipEventRecord(ev, s));
+        *done_event = ev;
+        return RTFB_OK;
+    }
+    BlockIO io;
+    PipeExt ext;
+    int rc = pipe_block(bank, out, ld_out, in, ld_in, n, tiled, &io, &ext);
+    if (rc || (rc = chain_prepare(bank, *g))) return rc;
+    ChainState &c = bank->chain;
+    if (*c.h_error) return chain_close(bank, s);
+    const int slot = (int)(c.seq % kChainRing), prev = (int)((c.seq + kChainRing - 1) % kChainRing);
+    hipStream_t x = c.s[c.seq & 1];
+    /* the link is ordered behind everything enqueued on the caller's stream so far (its input block) */
+    HIP_TRY(hipEventRecord(c.in_ready[slot], s));
+    HIP_TRY(hipStreamWaitEvent(x, c.in_ready[slot], 0));
+    ext.chain.my_queue = c.d_queue + (size_t)slot * c.count;
+    ext.chain.finished = c.d_counters + 16 * slot;
+    ext.chain.finished_base = c.finished_total[slot];
+    ext.chain.started = c.d_counters + 16 * (kChainRing + slot);
+    ext.chain.records = c.d_records;
+    ext.chain.gen = (unsigned int)(c.seq + 1);
+    ext.chain.error = c.d_error;
+    if (c.open) {
+        /* Gate: this launch may only be dispatched once every workgroup of the link before it (other stream) is
+         * resident -- and that link is itself behind its own input event, which this stream therefore waits for
+         * too, so that the gate never spins on a producer of the caller's. */
+        HIP_TRY(hipStreamWaitEvent(x, c.in_ready[prev], 0));
+        HIP_TRY(launch_chain_gate(c.d_counters + 16 * (kChainRing + prev), c.started_total[prev], c.d_error, x));
+        ext.chain.prev_queue = c.d_queue + (size_t)prev * c.count;
+    } else {
+        ext.chain.prev_queue = nullptr;     /* head of a chain: ordered behind `s` by the event above */
+    }
+    c.started_total[slot] += (unsigned long long)c.count;
+    c.finished_total[slot] += (unsigned long long)c.count;
+    HIP_TRY(launch_iir_pipe_ext(g->order, view_of(bank, *g), io, ext, x));
+    HIP_TRY(hipEventRecord(c.done[slot], x));
+    c.open = true;
+    c.links++;
+    c.seq++;
+    if (done_event) *done_event = c.done[slot];
+    return RTFB_OK;
+}
+
+int RTFilterBank_chain_join(RTFilterBank *bank, void *hip_stream)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    return chain_close(bank, static_cast<hipStream_t>(hip_stream));
+}
+
+int dsp_tile_rows(double *tiles, const double *rows, size_t ld, size_t nch, size_t n, void *hip_stream)
+{
+    if (!tiles || !rows) return fail(RTFB_EINVAL, "dsp_tile_rows: NULL argument");
+    if (n % RTFB_TILE || ld < n) return fail(RTFB_EINVAL, "dsp_tile_rows: n a multiple of RTFB_TILE, ld >= n");
+    HIP_TRY(launch_tile_rows(tiles, rows, ld, nch, n, 1, static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+int dsp_untile_rows(double *rows, size_t ld, const double *tiles, size_t nch, size_t n, void *hip_stream)
+{
+    if (!tiles || !rows) return fail(RTFB_EINVAL, "dsp_untile_rows: NULL argument");
+    if (n % RTFB_TILE || ld < n) return fail(RTFB_EINVAL, "dsp_untile_rows: n a multiple of RTFB_TILE, ld >= n");
+    HIP_TRY(launch_tile_rows(rows, tiles, ld, nch, n, 0, static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
 /* RTFilterBank_updaten on HOST arrays: for c: RTFilter_updaten(out + c*ld_out, filter_c, in + c*ld_in, n) as a
  * caller of the reference makes it, moved through the GPU in chunks of time (all channels x nt samples, so that
  * the carried state streams), through pinned staging rings.  Bounded by the host link and the CPU's copies. */
@@ -1637,7 +1936,18 @@ int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, si
                                  "at most 32*threads, dividing n");
     if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16) || ld_in % 2 || ld_out % 2)
         return fail(RTFB_EINVAL, "dsp_copy_rows: needs 16-byte aligned rows");
-    HIP_TRY(launch_copy_rows(out, ld_out, in, ld_in, nch, n, threads, seg, static_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(launch_copy_rows(out, ld_out, in, ld_in, nch, n, threads, seg, 0, static_cast<hipStream_t>(hip_stream)));
+    return RTFB_OK;
+}
+
+/* the same twin for the tiled block layout [n / RTFB_TILE][nch][RTFB_TILE]: workgroup c walks tile (s, c), s ascending */
+int dsp_copy_tiles(double *out, const double *in, size_t nch, size_t n, void *hip_stream)
+{
+    if (!out || !in) return fail(RTFB_EINVAL, "dsp_copy_tiles: NULL argument");
+    if (n % RTFB_TILE || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16))
+        return fail(RTFB_EINVAL, "dsp_copy_tiles: n a multiple of RTFB_TILE, 16-byte aligned blocks");
+    HIP_TRY(launch_copy_rows(out, RTFB_TILE, in, RTFB_TILE, nch, n, 256, RTFB_TILE, nch * (size_t)RTFB_TILE,
+                             static_cast<hipStream_t>(hip_stream)));
     return RTFB_OK;
 }
 
@@ -1662,6 +1972,10 @@ int RTFilterBank_reset(RTFilterBank *bank, void *hip_stream)
     if (!bank) return fail(RTFB_EINVAL, "NULL bank");
     DeviceScope ds(bank->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    {
+        int rc = chain_close(bank, static_cast<hipStream_t>(hip_stream));
+        if (rc) return rc;
+    }
     for (const Group &g : bank->groups)
         HIP_TRY(launch_reset(view_of(bank, g), static_cast<hipStream_t>(hip_stream)));
     return RTFB_OK;
@@ -1673,7 +1987,12 @@ int RTFilterBank_get_state(RTFilterBank *bank, double *state, double *fval, int3
     if (!bank) return fail(RTFB_EINVAL, "NULL bank");
     DeviceScope ds(bank->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    {
+        int rc = chain_close(bank, static_cast<hipStream_t>(hip_stream));
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    if (bank->chain.h_error && *bank->chain.h_error) return chain_close(bank, static_cast<hipStream_t>(hip_stream));
     const size_t ld = bank->state_ld;
     for (const Group &g : bank->groups) {
         const size_t cnt = g.chans.size();
@@ -1716,6 +2035,10 @@ int RTFilterBank_set_state(RTFilterBank *bank, const double *state, const double
     if (!bank) return fail(RTFB_EINVAL, "NULL bank");
     DeviceScope ds(bank->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    {
+        int rc = chain_close(bank, static_cast<hipStream_t>(hip_stream));
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
     const size_t ld = bank->state_ld;
     for (const Group &g : bank->groups) {

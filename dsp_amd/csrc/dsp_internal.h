@@ -77,11 +77,53 @@ struct BlockIO {
     int           aligned16;  /* in/out/ld allow 16-byte vector access */
 };
 
+/* Chained launches of the pipelined kernel (RTFilterBank_updaten_chained): consecutive blocks of a bank are
+ * launched on two alternating internal streams, and the workgroups of block k+1 take the slots that block k's
+ * workgroups free one by one instead of waiting for the whole launch to drain.  A workgroup of launch k+1 asks
+ * launch k's READY QUEUE for a channel whose block-k state is final (ticket = blockIdx.x: entry i is filled by the
+ * (i+1)-th workgroup of launch k that finishes), reads that channel's carried state from its CARRY RECORD and
+ * leaves the state after block k+1 there.  Every word that crosses between the two launches is self-validating:
+ *   queue entry   64 bits: (generation << 32) | (group-local channel + 1)        one 8-byte agent-scope store
+ *   carry record  per channel N+2 granules of 16 bytes {value, generation}        one 16-byte sc1 store each
+ * so a reader polls until the generation it expects shows up and needs no fence.  Generations grow by one per
+ * launch and never repeat during a bank's life. */
+struct ChainView {
+    const unsigned long long *prev_queue;  /* ready queue of the previous launch; nullptr = chain head: channel =
+                                              blockIdx.x, state from the group's plain arrays                       */
+    unsigned long long *my_queue;          /* this launch's ready queue (count entries)                            */
+    unsigned long long *finished;          /* cumulative count of published channels on my_queue's ring slot       */
+    unsigned long long finished_base;      /* its value before this launch                                         */
+    unsigned long long *started;           /* cumulative count of this ring slot's workgroups that have started:
+                                              the next launch is only enqueued behind a gate kernel that waits
+                                              for all of them (no workgroup may spin on one that is not resident) */
+    double *records;                       /* count x (N + 2) granules {value, generation}: s[0..N], filtered_value */
+    unsigned int gen;                      /* generation this launch writes; it reads gen - 1                      */
+    unsigned int *error;                   /* set to nonzero when a bounded wait ran out                           */
+};
+
+/* What only the pipelined kernel knows how to use. */
+struct PipeExt {
+    size_t seg_in, seg_out;                /* doubles between consecutive 2048-sample segments of a channel's block:
+                                              2048 for rows; nch * 2048 in the tiled block layout
+                                              [segment][channel][2048] (then BlockIO.ld_* = 2048)                  */
+    ChainView chain;                       /* chain.records == nullptr: an ordinary launch                         */
+};
+
 /* launchers (kernels.hip).  Each returns the hipError_t of the launch. */
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan2(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_pipe(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
+/* the pipelined kernel on whole, 16-byte aligned segments with a segment stride (tiled layout) and / or as one
+ * link of a chain; g.count must not exceed pipe_resident_round() for a chained launch */
+hipError_t launch_iir_pipe_ext(int order, const GroupView &g, const BlockIO &io, const PipeExt &ext, hipStream_t s);
+int pipe_resident_round();
+hipError_t launch_chain_gate(const unsigned long long *started, unsigned long long target, unsigned int *error,
+                             hipStream_t s);
+hipError_t launch_chain_unpack(const double *records, double *state, double *fval, int32_t *init, int count, int N,
+                               int state_ld, hipStream_t s);
+hipError_t launch_tile_rows(double *dst, const double *src, size_t ld, size_t nch, size_t n, int to_tiles,
+                            hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 /* false when launch_fir takes the lane-per-channel kernel, which updates g.state in place (no ping-pong swap) */
@@ -91,7 +133,7 @@ hipError_t launch_synth(double *dst, size_t ld, size_t nch, size_t n, uint64_t s
                         uint64_t chan0, uint64_t n0, hipStream_t s);
 
 hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
-                            size_t n, int threads, int seg, hipStream_t s);
+                            size_t n, int threads, int seg, size_t seg_stride, hipStream_t s);
 hipError_t launch_state_pack(double *pack, const double *state, const double *fval, const int32_t *init,
                              int ld, hipStream_t s);
 hipError_t launch_state_unpack(const double *pack, double *state, double *fval, int32_t *init, int ld,

@@ -915,8 +915,10 @@ __global__ void synth_kernel(double *dst, size_t ld, size_t nch, size_t n, uint6
  * loads and stores.  Gives the HBM ceiling OF THIS PATTERN to read roofline fractions against. */
 template <int kThreads, int kNT = 0>
 __global__ void __launch_bounds__(kThreads)
-copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, size_t n, int seg)
+copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, size_t n, int seg, size_t seg_stride)
 {
+    /* seg_stride: doubles between consecutive pieces of a row (== seg for rows; nch * seg in the tiled block
+     * layout, where ld_* = seg) */
     const double *src = in + (size_t)blockIdx.x * ld_in;
     double *dst = out + (size_t)blockIdx.x * ld_out;
     const int per = seg / 2 / kThreads;              /* 16-byte pieces per thread per segment (<= 16) */
@@ -926,7 +928,7 @@ copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, siz
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (i < per) {
-                const d2 *p = reinterpret_cast<const d2 *>(src + base + 2 * (i * kThreads + threadIdx.x));
+                const d2 *p = reinterpret_cast<const d2 *>(src + base / seg * seg_stride + 2 * (i * kThreads + threadIdx.x));
                 buf[i] = (kNT & 1) ? __builtin_nontemporal_load(p) : *p;
             }
     };
@@ -935,7 +937,7 @@ copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, siz
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (i < per) {
-                d2 *p = reinterpret_cast<d2 *>(dst + base + 2 * (i * kThreads + threadIdx.x));
+                d2 *p = reinterpret_cast<d2 *>(dst + base / seg * seg_stride + 2 * (i * kThreads + threadIdx.x));
                 if (kNT & 2) __builtin_nontemporal_store(buf[i], p);
                 else *p = buf[i];
             }
@@ -951,16 +953,17 @@ copy_rows_kernel(double *out, size_t ld_out, const double *in, size_t ld_in, siz
 }
 
 hipError_t launch_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
-                            size_t n, int threads, int seg, hipStream_t s)
+                            size_t n, int threads, int seg, size_t seg_stride, hipStream_t s)
 {
+    if (!seg_stride) seg_stride = (size_t)seg;
     /* the 256-thread variant carries the nontemporal hint on both sides like the filter kernels (the faster
      * copy: 5.10 vs 4.89 TB/s, either side alone 1 %) */
     if (threads == 256)
-        hipLaunchKernelGGL((copy_rows_kernel<256, 3>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg);
+        hipLaunchKernelGGL((copy_rows_kernel<256, 3>), dim3((unsigned)nch), dim3(256), 0, s, out, ld_out, in, ld_in, n, seg, seg_stride);
     else if (threads == 64)
-        hipLaunchKernelGGL(copy_rows_kernel<64>, dim3((unsigned)nch), dim3(64), 0, s, out, ld_out, in, ld_in, n, seg);
+        hipLaunchKernelGGL(copy_rows_kernel<64>, dim3((unsigned)nch), dim3(64), 0, s, out, ld_out, in, ld_in, n, seg, seg_stride);
     else
-        hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg);
+        hipLaunchKernelGGL(copy_rows_kernel<128>, dim3((unsigned)nch), dim3(128), 0, s, out, ld_out, in, ld_in, n, seg, seg_stride);
     return hipGetLastError();
 }
 

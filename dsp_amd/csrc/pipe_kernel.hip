@@ -63,10 +63,52 @@ __device__ __forceinline__ void rotate_priority(int k)
     }
 }
 
-template <int N, bool kUnitA0, bool kWhole>
-__global__ void __launch_bounds__(2 * kWave, 2)
-iir_pipe_kernel(GroupView g, BlockIO io)
+/* ---- chained launches (ChainView, dsp_internal.h) ------------------------------------------------------- */
+
+constexpr unsigned long long kChainTimeoutTicks = 200000000ull;      /* 2 s of the 100 MHz realtime counter */
+
+/* One 16-byte granule {value, generation}, written by ONE 16-byte sc1 (write-through) store and read by one
+ * 16-byte sc1 load (served by L2 / memory, never by this CU's L1): a reader polls until the generation it
+ * expects shows up (observed untorn on gfx950; MI355X_MICROARCH.md, "R2's granule needs no ordering at all"). */
+__device__ __forceinline__ d2 granule_load(const double *p)
 {
+    d2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void granule_store(double *p, double value, unsigned int gen)
+{
+    d2 v;
+    v.x = value;
+    v.y = __longlong_as_double((long long)(unsigned long long)gen);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned int granule_gen(d2 v) { return (unsigned int)__double_as_longlong(v.y); }
+
+/* Lane i (i < cnt) of the calling wave fetches granule i of a record; returns once all cnt carry generation
+ * `want` (bounded: after ~2 s the error word is raised and whatever was read is returned). */
+__device__ __forceinline__ d2 record_load(const double *rec, int cnt, unsigned int want, unsigned int *error)
+{
+    const int lane = threadIdx.x & 63;
+    const double *p = rec + 2 * (lane < cnt ? lane : cnt - 1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const d2 v = granule_load(p);
+        if (__all(granule_gen(v) == want)) return v;
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) {
+            if (lane == 0) __hip_atomic_store(error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        }
+    }
+}
+
+/* kChain (whole-segment launches only): the launch is one link of a chain, see ChainView. */
+template <int N, bool kUnitA0, bool kWhole, bool kChain>
+__global__ void __launch_bounds__(2 * kWave, 2)
+iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
+{
+    static_assert(kWhole || !kChain, "chained launches consist of whole segments");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile0 = smem;
     char *tile1 = smem + kPTile;
@@ -80,7 +122,41 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const bool front = tid < kWave;
-    const int gi = blockIdx.x;
+    int gi = blockIdx.x;
+    bool chain_tail = false;                                /* state comes from a carry record, not from g.state */
+    if constexpr (kChain) {
+        if (tid == 0)
+            __hip_atomic_fetch_add(ext.chain.started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ext.chain.prev_queue) {
+            /* ticket = blockIdx.x: the channel that the (blockIdx.x + 1)-th finisher of the previous launch
+             * published.  One poller; the decision (a channel, or give up) reaches both waves through LDS. */
+            chain_tail = true;
+            int *slot = reinterpret_cast<int *>(smem);
+            if (tid == 0) {
+                const unsigned long long *q = ext.chain.prev_queue + blockIdx.x;
+                const unsigned int want = ext.chain.gen - 1;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                int got = -1;
+                for (;;) {
+                    const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(v >> 32) == want) {
+                        got = (int)(unsigned int)v - 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) {
+                        __hip_atomic_store(ext.chain.error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                if (got >= g.count) got = -1;
+                slot[0] = got;
+            }
+            lds_barrier();
+            gi = __builtin_amdgcn_readfirstlane(slot[0]);
+            if (gi < 0) return;                             /* both waves: the chain is broken, host reports it */
+        }
+    }
     const int prio_slot = (int)(blockIdx.x >> 8);
     const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
     const int dsn = as_const(g.design)[gi];
@@ -108,7 +184,20 @@ iir_pipe_kernel(GroupView g, BlockIO io)
     double *dst = io.out + (size_t)chan * io.ld_out;
     /* wave-uniform words of this launch's inputs come through scalar loads: a vector load issued next to the
      * segment prefetch below would make its first use wait for the whole prefetch (vmcnt counts in order) */
-    const bool seed_stream = as_const(g.init)[gi] != 0;
+    bool seed_stream = as_const(g.init)[gi] != 0;
+    double tail0 = as_const(g.state)[(size_t)gi * g.state_ld + N];     /* s[N]: read, never written */
+    double *rec = nullptr;
+    if constexpr (kChain) {
+        rec = ext.chain.records + (size_t)gi * (2 * (N + 2));
+        /* behind at least one whole block the stream is initialised; s[N] rides in the record (the head launch
+         * may have zeroed it) and reaches the front wave through LDS: the back wave, idle until segment 0 is
+         * published, reads the record while the front's prefetch is in flight */
+        if (chain_tail) seed_stream = false;
+    }
+    /* two words behind the start-state slots (chained launches only): [0] s[N] from the record, back -> front
+     * before the first barrier; [1] this channel's position in the ready queue, front -> back */
+    double *xch = reinterpret_cast<double *>(smem + 2 * kPTile) + kPRows * (N + 2);
+    const size_t seg_in = kWhole ? ext.seg_in : (size_t)kPSeg, seg_out = kWhole ? ext.seg_out : (size_t)kPSeg;
 
     /* The front wave's first two segments are requested before anything else: the table loads below
      * then run under the cold-start HBM latency instead of in front of it. */
@@ -134,7 +223,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
         if constexpr (kWhole) {
             static_assert(kPPieces == 16, "four base pointers x four 1 KiB offsets");
-            const double *p0 = src + base + 2 * lane;          /* piece i of the lane: + i * 1024 bytes */
+            const double *p0 = src + (size_t)seg * seg_in + 2 * lane;   /* piece i of the lane: + i * 1024 bytes */
             const double *p1 = p0 + 4 * 2 * kWave, *p2 = p0 + 8 * 2 * kWave, *p3 = p0 + 12 * 2 * kWave;
             asm volatile(
                 "global_load_dwordx4 %0, %16, off nt\n\t"
@@ -232,7 +321,6 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             a[i] = cf[N + 1 + i];
         }
     };
-    const double tail0 = as_const(g.state)[(size_t)gi * g.state_ld + N];   /* s[N]: read, never written */
 
     if (front) {
         /* =============================== FRONT =============================== */
@@ -262,6 +350,9 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             }
             lds_barrier();                                    /* barrier 1 */
             if (it >= nseg) return;
+            if constexpr (kChain) {
+                if (chain_tail && it == 0) tail0 = xch[0];
+            }
             if (it == 0) stamp(7);
             if (it == 8) stamp(12);
             if (it == 9) stamp(23);
@@ -398,6 +489,17 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 #pragma unroll
                 for (int i = 0; i < N; ++i) slot[i] = v[i];
             }
+            if constexpr (kChain) {
+                /* The front wave is done one segment before the back wave: it claims the channel's position in
+                 * the ready queue now, so that the returning atomic is not waited for at the very end, where the
+                 * workgroup would hold its slot idle for the round trip. */
+                if (it == nseg - 1 && lane == 0) {
+                    const unsigned long long pos =
+                        __hip_atomic_fetch_add(ext.chain.finished, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                        ext.chain.finished_base;
+                    xch[1] = (double)pos;
+                }
+            }
             if (it == 0) stamp(2);                            /* segment 0 published */
             if (it == 8) {
                 stamp(14);
@@ -414,12 +516,19 @@ iir_pipe_kernel(GroupView g, BlockIO io)
         double b[N + 1], a[N + 1];
         load_coefs(b, a);
         double carry[N + 1];
-        {
+        double ylast;
+        if (kChain && chain_tail) {
+            const d2 gv = record_load(rec, N + 2, ext.chain.gen - 1, ext.chain.error);
+#pragma unroll
+            for (int i = 0; i <= N; ++i) carry[i] = __shfl(gv.x, i, kWave);
+            ylast = __shfl(gv.x, N + 1, kWave);
+            if (lane == 0) xch[0] = carry[N];             /* for the front wave, read behind the first barriers */
+        } else {
             const double *st = g.state + (size_t)gi * g.state_ld;
 #pragma unroll
             for (int i = 0; i <= N; ++i) carry[i] = st[i];
+            ylast = g.fval[gi];
         }
-        double ylast = g.fval[gi];
         /* this lane's propagator A^(32*lane), row-major, resident for the whole launch */
         double tp[N * N];
         {
@@ -448,12 +557,16 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 #pragma unroll
         for (int e = (N * N) / 8 * 8; e < N * N; ++e) asm volatile("" ::"v"(tp[e]));
         asm volatile("" ::"v"(ylast));
+        double qpos = 0.0;
         for (int it = 1; it <= nseg; ++it) {
             const int seg = it - 1;
             char *tile = (seg & 1) ? tile1 : tile0;
             rotate_priority(prio_slot + it);
             if (seg == 9) stamp(19);
             lds_barrier();                                    /* barrier 0 */
+            if constexpr (kChain) {
+                if (it == nseg) qpos = xch[1];
+            }
             double s[N + 1];
             {
                 const double *slot = pbuf + lane * kPPitch;
@@ -529,9 +642,10 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             if (seg == 8) stamp(18);
             wave_sync();
             if (kWhole || (seg_len == kPSeg && io.aligned16)) {
+                double *drow = dst + (size_t)seg * seg_out;
 #pragma unroll 8
                 for (int i = 0; i < kPPieces; ++i)
-                    stream_store(reinterpret_cast<d2 *>(dst + base + 2 * (i * kWave + lane)),
+                    stream_store(reinterpret_cast<d2 *>(drow + 2 * (i * kWave + lane)),
                                  *reinterpret_cast<const d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]));
             } else {
 #pragma unroll 4
@@ -544,7 +658,23 @@ iir_pipe_kernel(GroupView g, BlockIO io)
             }
         }
 
-        if (lane == 0) {
+        if constexpr (kChain) {
+            /* The state after this block goes into the channel's carry record (lane i: granule i) and the channel
+             * joins the ready queue at the position the front wave claimed.  No wait and no order between the
+             * two: the record's granules validate themselves, a reader that finds the queue entry first polls
+             * them. */
+            double val = ylast;
+#pragma unroll
+            for (int i = 0; i <= N; ++i) val = lane == i ? carry[i] : val;
+            if (lane < N + 2) granule_store(rec + 2 * lane, val, ext.chain.gen);
+            if (lane == 0) {
+                const unsigned long long pos = (unsigned long long)qpos;
+                if (pos < (unsigned long long)g.count)
+                    __hip_atomic_store(ext.chain.my_queue + pos,
+                                       ((unsigned long long)ext.chain.gen << 32) | (unsigned int)(gi + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (lane == 0) {
             double *st = g.state + (size_t)gi * g.state_ld;
 #pragma unroll
             for (int i = 0; i <= N; ++i) st[i] = carry[i];
@@ -556,7 +686,7 @@ iir_pipe_kernel(GroupView g, BlockIO io)
 }
 
 /* workgroups of the pipelined kernel the device holds at once (4 per CU: two 16 KiB tiles each, 2 waves per SIMD) */
-static int pipe_resident_round()
+int pipe_resident_round()
 {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -598,14 +728,118 @@ static hipError_t launch_pipe_one(const GroupView &g, const BlockIO &io, hipStre
 {
     const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * (N + 2);
     const bool whole = io.aligned16 && io.n % kPSeg == 0;
+    PipeExt ext = {};
+    ext.seg_in = ext.seg_out = kPSeg;
     if (g.unit_a0 && whole)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
     else if (g.unit_a0)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, false, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
     else if (whole)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
     else
-        hipLaunchKernelGGL((iir_pipe_kernel<N, false, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, false, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
+    return hipGetLastError();
+}
+
+/* whole segments with a segment stride and / or as a link of a chain */
+template <int N>
+static hipError_t launch_pipe_ext(const GroupView &g, const BlockIO &io, const PipeExt &ext, hipStream_t s)
+{
+    const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * (N + 2);
+    if (!io.aligned16 || io.n % kPSeg || ext.seg_in % 2 || ext.seg_out % 2) return hipErrorInvalidValue;
+    if (ext.chain.records) {
+        if (g.count > pipe_resident_round()) return hipErrorInvalidValue;
+        const size_t ldc = lds + 16;                        /* + the two exchange words */
+        if (g.unit_a0)
+            hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, true>), dim3(g.count), dim3(2 * kWave), ldc, s, g, io, ext);
+        else
+            hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, true>), dim3(g.count), dim3(2 * kWave), ldc, s, g, io, ext);
+    } else if (g.unit_a0)
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
+    else
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
+    return hipGetLastError();
+}
+
+hipError_t launch_iir_pipe_ext(int order, const GroupView &g, const BlockIO &io, const PipeExt &ext, hipStream_t s)
+{
+    switch (order) {
+        case 1: return launch_pipe_ext<1>(g, io, ext, s);
+        case 2: return launch_pipe_ext<2>(g, io, ext, s);
+        case 3: return launch_pipe_ext<3>(g, io, ext, s);
+        case 4: return launch_pipe_ext<4>(g, io, ext, s);
+        case 5: return launch_pipe_ext<5>(g, io, ext, s);
+        case 6: return launch_pipe_ext<6>(g, io, ext, s);
+        case 7: return launch_pipe_ext<7>(g, io, ext, s);
+        case 8: return launch_pipe_ext<8>(g, io, ext, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+/* ---- chain plumbing: gate, unpack ------------------------------------------------------------------------- */
+
+/* Runs on the stream of launch k+1 in front of it: returns once every workgroup of launch k (the other stream)
+ * has started, so that no workgroup of k+1 can occupy a slot a workgroup of k still needs.  One lane, bounded. */
+__global__ void __launch_bounds__(kWave) chain_gate_kernel(const unsigned long long *started,
+                                                            unsigned long long target, unsigned int *error)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kChainTimeoutTicks) {
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+hipError_t launch_chain_gate(const unsigned long long *started, unsigned long long target, unsigned int *error,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(kWave), 0, s, started, target, error);
+    return hipGetLastError();
+}
+
+/* carry records -> the group's plain arrays (end of a chain; ordinary stream order, all links complete) */
+__global__ void __launch_bounds__(256) chain_unpack_kernel(const double *records, double *state, double *fval,
+                                                            int32_t *init, int count, int N, int state_ld)
+{
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= count) return;
+    const double *rec = records + (size_t)gi * (2 * (N + 2));
+    for (int i = 0; i <= N; ++i) state[(size_t)gi * state_ld + i] = rec[2 * i];
+    fval[gi] = rec[2 * (N + 1)];
+    init[gi] = 0;
+}
+
+hipError_t launch_chain_unpack(const double *records, double *state, double *fval, int32_t *init, int count, int N,
+                               int state_ld, hipStream_t s)
+{
+    hipLaunchKernelGGL(chain_unpack_kernel, dim3((count + 255) / 256), dim3(256), 0, s, records, state, fval, init,
+                       count, N, state_ld);
+    return hipGetLastError();
+}
+
+/* rows [nch][ld] <-> tiles [n / 2048][nch][2048] (harness / caller helper: dsp_tile_rows, dsp_untile_rows) */
+__global__ void __launch_bounds__(256) tile_rows_kernel(double *dst, const double *src, size_t ld, size_t nch,
+                                                         size_t nseg, int to_tiles)
+{
+    const size_t c = blockIdx.x, sg = blockIdx.y;
+    const double *row = (to_tiles ? src : dst) + c * ld + sg * kPSeg;
+    const double *tl = (to_tiles ? dst : src) + (sg * nch + c) * kPSeg;
+    for (int k = threadIdx.x; k < kPSeg; k += 256) {
+        if (to_tiles) const_cast<double *>(tl)[k] = row[k];
+        else const_cast<double *>(row)[k] = tl[k];
+    }
+}
+
+hipError_t launch_tile_rows(double *dst, const double *src, size_t ld, size_t nch, size_t n, int to_tiles,
+                            hipStream_t s)
+{
+    if (n % kPSeg || nch == 0 || n == 0 || n / kPSeg > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)nch, (unsigned)(n / kPSeg)), dim3(256), 0, s, dst, src, ld,
+                       nch, n / kPSeg, to_tiles);
     return hipGetLastError();
 }
 

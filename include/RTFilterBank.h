@@ -142,6 +142,45 @@ EXPORT int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t 
                                         const double *in, size_t ld_in, size_t n, void *hip_stream);
 EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
 
+/* ---- tiled block layout, chained block updates (no counterpart in the reference) ---------------------------
+ * Both serve the streaming form of RTFilter_updaten (ref: src/RTFilter.c:111-119 called block after block on the
+ * same filters) on banks that the pipelined IIR kernel runs: ONE launch group of IIR channels of order <= 8
+ * (na == nb), at most 1024 distinct designs, admitted by the conditioning probe (or RTFB_MODE_SCAN).  Results are
+ * the bits RTFilterBank_updaten produces for the same blocks.
+ *
+ * TILED LAYOUT.  A block of n samples (n a multiple of RTFB_TILE) of all nch channels is stored
+ * [n / RTFB_TILE][nch][RTFB_TILE]: sample k of channel c at ((k / RTFB_TILE) * nch + c) * RTFB_TILE + k % RTFB_TILE.
+ * The workgroups that run together then sweep one contiguous window of HBM per step instead of nch streams a row
+ * pitch apart (measured on the copy twin: 5.9 vs 5.45 TB/s at 1024 x 64K, profiles/r3_tiled_copy.txt).  in == out
+ * is allowed.  dsp_tile_rows / dsp_untile_rows convert between rows (pitch ld) and tiles on the device.
+ * Other banks: RTFB_EUNSUPPORTED. */
+#define RTFB_TILE 2048
+EXPORT int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream);
+EXPORT int dsp_tile_rows(double *tiles, const double *rows, size_t ld, size_t nch, size_t n, void *hip_stream);
+EXPORT int dsp_untile_rows(double *rows, size_t ld, const double *tiles, size_t nch, size_t n, void *hip_stream);
+
+/* CHAINED UPDATES.  RTFilterBank_updaten launches block k+1 behind block k in stream order, so every launch fills
+ * and drains the GPU alone (8 % of a 64K-sample step of a 1024-channel bank).  _updaten_chained enqueues the
+ * blocks of a stream on two internal streams of the bank instead: the workgroups of block k+1 take the slots that
+ * block k's workgroups free one by one, each picking a channel whose block-k state is final (a ready queue and
+ * per-channel carry records in HBM; dsp_internal.h: ChainView).  Same arguments as _updaten plus
+ *   flags        RTFB_CHAIN_TILED: in / out are in the tiled layout above (ld_* ignored)
+ *   done_event   if not NULL: receives a hipEvent_t (owned by the bank, valid until four more chained calls)
+ *                that completes when this block's outputs are written.
+ * Ordering: the call is ordered behind everything enqueued on `hip_stream` before it (the producer of `in`);
+ * nothing enqueued on `hip_stream` afterwards waits for it -- consumers wait on done_event, or call
+ * RTFilterBank_chain_join(bank, stream), which makes `stream` wait for all chained calls so far.  Every other
+ * entry point of the bank (updaten, reset, get/set_state, sync_to_host, destroy) joins first on the stream it is
+ * given.  n must be a multiple of RTFB_TILE, rows 16-byte aligned, and the bank no wider than the workgroups the
+ * GPU holds at once (1024 on MI355X); a call that does not qualify runs in stream order on `hip_stream` with the
+ * same results (done_event still valid).  One thread drives a bank's chain.  All waits between launches are
+ * bounded (2 s): if one runs out the bank reports RTFB_EDEVICE from the next call and must be rebuilt. */
+#define RTFB_CHAIN_TILED 1u
+EXPORT int RTFilterBank_updaten_chained(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
+                                        size_t ld_in, size_t n, unsigned flags, void *hip_stream,
+                                        void **done_event);
+EXPORT int RTFilterBank_chain_join(RTFilterBank *bank, void *hip_stream);
+
 /* The same loop for HOST arrays -- what an unchanged caller of the reference holds: in/out are ordinary
  * (pageable) host memory, channel-major, ld_* in doubles, in == out allowed.  The block is moved through the GPU in
  * chunks of time (all channels x nt samples each, so the carried state streams from chunk to chunk): the CPU
@@ -219,6 +258,8 @@ EXPORT int dsp_synth_fill(double *dst, size_t ld, size_t nch, size_t n,
  * roofline fraction.  threads in {64,128,256}; seg divides n; rows 16-byte aligned. */
 EXPORT int dsp_copy_rows(double *out, size_t ld_out, const double *in, size_t ld_in, size_t nch,
                          size_t n, int threads, int seg, void *hip_stream);
+/* dsp_copy_rows for the tiled block layout [n / RTFB_TILE][nch][RTFB_TILE] (256 threads, one tile per piece). */
+EXPORT int dsp_copy_tiles(double *out, const double *in, size_t nch, size_t n, void *hip_stream);
 EXPORT int dsp_device_count(void);
 EXPORT int dsp_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, int device);
 EXPORT int dsp_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, int device);

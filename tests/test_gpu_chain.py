@@ -1,0 +1,158 @@
+"""The tiled block layout and the chained block updates (include/RTFilterBank.h: RTFilterBank_updaten_tiled,
+RTFilterBank_updaten_chained) against RTFilterBank_updaten and the oracle.  Both entry points run the pipelined
+IIR kernel with the same arithmetic in the same order, so their outputs are held to the BITS of
+RTFilterBank_updaten on the same blocks; that entry in turn is held to 1e-12 of the oracle (the re-associated
+kernel's bar), and so are these."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def G():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _bank(G, key, nch, mode=None):
+    from dsp_amd import bank as gbank
+    return gbank.FilterBank([G.golden_design(key)], [0] * nch, mode=gbank.MODE_AUTO if mode is None else mode)
+
+
+def _oracle_rows(G, key, x):
+    from oracle import oracle as orc
+    d = G.to_orc_design(G.golden_design(key))
+    ob = orc.Bank([d], [0] * x.shape[0])
+    return ob.updaten(x, threads=8), ob
+
+
+def test_tile_round_trip(G):
+    import torch
+    from dsp_amd import bank as gbank
+    x = torch.rand((37, 3 * gbank.TILE), dtype=torch.float64, device="cuda")
+    t = gbank.tile_rows(x)
+    assert t.shape == (3, 37, gbank.TILE)
+    assert torch.equal(t[1, 5], x[5, gbank.TILE:2 * gbank.TILE])
+    assert torch.equal(gbank.untile_rows(t), x)
+
+
+@pytest.mark.parametrize("key,nch", [("bw4_bp_0.3_0.6", 96), ("bw4_lp_0.5", 40), ("bw5_lp_0.25", 17)])
+def test_tiled_layout_matches_rows_to_the_bit(G, key, nch):
+    """Blocks of 3, 1 and 5 tiles, state carried; in place for the last block."""
+    import torch
+    from dsp_amd import bank as gbank
+    blocks = [3 * gbank.TILE, gbank.TILE, 5 * gbank.TILE]
+    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    pos = 0
+    ys = []
+    for i, n in enumerate(blocks):
+        x = G.to_dev(G.make_inputs(77, nch, n, pos))
+        want = a_bank(x)
+        xt = gbank.tile_rows(x)
+        yt = xt if i == 2 else torch.empty_like(xt)
+        b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        got = gbank.untile_rows(yt)
+        assert torch.equal(got, want), (key, i)
+        ys.append(got.cpu().numpy())
+        pos += n
+    want_o, ob = _oracle_rows(G, key, G.make_inputs(77, nch, sum(blocks), 0))
+    assert util.rel_to_peak(np.concatenate(ys, axis=1), want_o).max() <= TOL
+    sa, sb = a_bank.get_state(), b_bank.get_state()
+    for p, q in zip(sa, sb):
+        assert util.bits_equal(p, q)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("key,nch", [("bw4_bp_0.3_0.6", 1024), ("bw4_bp_0.3_0.6", 300), ("bw5_lp_0.25", 64)])
+def test_chained_blocks_match_stream_order_to_the_bit(G, key, nch, tiled):
+    """Twelve blocks of 4 tiles through the chain (fresh stream: the head launch runs stable_init), a join in the
+    middle (get_state), then more blocks: outputs, end state, filtered_value and initialized equal those of
+    RTFilterBank_updaten on the same blocks bit for bit; the whole stream within 1e-12 of the oracle."""
+    import torch
+    from dsp_amd import bank as gbank
+    n, nblocks = 4 * gbank.TILE, 12
+    x = G.to_dev(G.make_inputs(91, nch, n * nblocks, 0))
+    ref_bank, ch_bank = _bank(G, key, nch), _bank(G, key, nch)
+    want = torch.empty_like(x)
+    for j in range(nblocks):
+        ref_bank.updaten_ptr(want.data_ptr() + j * n * 8, x.stride(0), x.data_ptr() + j * n * 8, x.stride(0), n)
+    got = torch.empty_like(x)
+    events = []
+
+    def run(j):
+        if tiled:
+            xt = gbank.tile_rows(x[:, j * n:(j + 1) * n])
+            yt = torch.empty_like(xt)
+            events.append((ch_bank.updaten_chained_ptr(yt.data_ptr(), 0, xt.data_ptr(), 0, n, tiled=True,
+                                                       want_event=True), j, yt, xt))
+        else:
+            events.append((ch_bank.updaten_chained_ptr(got.data_ptr() + j * n * 8, got.stride(0),
+                                                       x.data_ptr() + j * n * 8, x.stride(0), n, want_event=True),
+                           j, None, None))
+
+    for j in range(7):
+        run(j)
+    st_mid = ch_bank.get_state()                     # joins the chain, synchronises
+    assert st_mid[2].max() == 0
+    for j in range(7, nblocks):
+        run(j)
+    ch_bank.chain_join()
+    torch.cuda.synchronize()
+    if tiled:
+        for ev, j, yt, _ in events:
+            assert ev is not None
+            got[:, j * n:(j + 1) * n] = gbank.untile_rows(yt)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), (key, nch, tiled)
+    for p, q in zip(ref_bank.get_state(), ch_bank.get_state()):
+        assert util.bits_equal(p, q)
+    want_o, ob = _oracle_rows(G, key, x.cpu().numpy())
+    assert util.rel_to_peak(got.cpu().numpy(), want_o).max() <= TOL
+
+
+def test_chained_call_that_does_not_qualify_runs_in_stream_order(G):
+    """A ragged block length, a sequential-mode bank and a FIR bank: same results as RTFilterBank_updaten,
+    done_event valid."""
+    import torch
+    from dsp_amd import bank as gbank
+    nch = 48
+    for key, mode, n in (("bw4_bp_0.3_0.6", gbank.MODE_AUTO, 5000), ("bw4_bp_0.3_0.6", gbank.MODE_SEQUENTIAL, 4096),
+                         ("fir32_lp_0.25", gbank.MODE_AUTO, 4096)):
+        x = G.to_dev(G.make_inputs(5, nch, 2 * n, 0))
+        a_bank, b_bank = _bank(G, key, nch, mode), _bank(G, key, nch, mode)
+        want, got = torch.empty_like(x), torch.empty_like(x)
+        for j in range(2):
+            a_bank.updaten_ptr(want.data_ptr() + j * n * 8, 2 * n, x.data_ptr() + j * n * 8, 2 * n, n)
+            ev = b_bank.updaten_chained_ptr(got.data_ptr() + j * n * 8, 2 * n, x.data_ptr() + j * n * 8, 2 * n, n,
+                                            want_event=True)
+            assert ev
+        b_bank.chain_join()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), key
+
+
+def test_chain_then_reset_then_chain(G):
+    """RTFilter_reset between two chains (the benchmark's wrap): the second chain's head runs stable_init again."""
+    import torch
+    from dsp_amd import bank as gbank
+    key, nch, n = "bw4_bp_0.3_0.6", 128, 2 * gbank.TILE
+    x = G.to_dev(G.make_inputs(17, nch, 3 * n, 0))
+    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    want, got = torch.empty((2,) + tuple(x.shape), dtype=torch.float64, device="cuda"), None
+    got = torch.empty_like(want)
+    for rep in range(2):
+        for j in range(3):
+            a_bank.updaten_ptr(want[rep].data_ptr() + j * n * 8, 3 * n, x.data_ptr() + j * n * 8, 3 * n, n)
+            b_bank.updaten_chained_ptr(got[rep].data_ptr() + j * n * 8, 3 * n, x.data_ptr() + j * n * 8, 3 * n, n)
+        a_bank.reset()
+        b_bank.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(got[0], got[1])

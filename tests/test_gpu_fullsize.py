@@ -209,6 +209,38 @@ def test_config2_every_channel_every_sample_vs_oracle(G):
         torch.cuda.synchronize()
         ys[name] = y[:, :L]
         bank.close()
+    # the same 16 blocks through the tiled layout (as benchmarked) and through the chained entry in both layouts:
+    # the bits of RTFilterBank_updaten's scan kernel on every channel and sample, hence the oracle's to 1e-12 below
+    for name, tiled, chained in (("tiled", True, False), ("tiled+chained", True, True), ("rows+chained", False, True)):
+        bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * C_)
+        xt = torch.empty((B // gbank.TILE, C_, gbank.TILE), dtype=torch.float64, device="cuda")
+        yt = [torch.empty_like(xt) for _ in range(2)]
+        yr = torch.empty((C_, B), dtype=torch.float64, device="cuda")
+        for j in range(L // B):
+            xj = x[:, j * B:(j + 1) * B]
+            if tiled:
+                gbank.tile_rows(xj, xt)
+                if chained:
+                    bank.updaten_chained_ptr(yt[j & 1].data_ptr(), 0, xt.data_ptr(), 0, B, tiled=True)
+                    bank.chain_join()              # xt is refilled for the next block
+                else:
+                    bank.updaten_tiled_ptr(yt[j & 1].data_ptr(), xt.data_ptr(), B)
+                gbank.untile_rows(yt[j & 1], yr)
+            else:
+                bank.updaten_chained_ptr(yr.data_ptr(), B, xj.data_ptr(), pitch, B)
+                bank.chain_join()
+            assert torch.equal(yr, ys["scan"][:, j * B:(j + 1) * B]), (name, j)
+        bank.close()
+    # sixteen chained blocks in flight back to back (no join in between), rows layout, straight into a 2^20 buffer
+    bank = gbank.FilterBank([gbank.iir_design(b, a)], [0] * C_)
+    yc = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+    for j in range(L // B):
+        bank.updaten_chained_ptr(yc.data_ptr() + j * B * 8, pitch, x.data_ptr() + j * B * 8, pitch, B)
+    bank.chain_join()
+    torch.cuda.synchronize()
+    assert torch.equal(yc[:, :L], ys["scan"])
+    bank.close()
+    del yc
     step = 128
     worst = 0.0
     for c0 in range(0, C_, step):

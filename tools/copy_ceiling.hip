@@ -135,6 +135,69 @@ __global__ void __launch_bounds__(1024) copy_rows(const d2 *__restrict__ in, d2 
     }
 }
 
+/* tiled block layout [segment][row][T*U pieces]: workgroup r walks segment s of its row at (s * rows + r) * seg16 --
+ * the workgroups that run together then sweep one contiguous window of rows * 16 KiB per step */
+template <bool NT, int U>
+__global__ void __launch_bounds__(1024) copy_rows_tiled(const d2 *__restrict__ in, d2 *__restrict__ out, size_t rows,
+                                                         size_t row16)
+{
+    const size_t T = blockDim.x;
+    const size_t seg16 = T * U;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        d2 cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = ld<NT>(in + r * seg16 + threadIdx.x + u * T);
+        const size_t nseg = row16 / seg16;
+        for (size_t s = 0; s < nseg; ++s) {
+            const bool more = s + 1 < nseg;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = ld<NT>(in + ((s + 1) * rows + r) * seg16 + threadIdx.x + u * T);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) st<NT>(out + (s * rows + r) * seg16 + threadIdx.x + u * T, cur[u]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            }
+        }
+    }
+}
+
+/* the tiled sweep with the workgroups out of step: workgroup r starts at segment (hash(r) % spread) and wraps
+ * (what chained launches do to the lock-step of a launch: round 3) */
+template <bool NT, int U>
+__global__ void __launch_bounds__(1024) copy_rows_tiled_desync(const d2 *__restrict__ in, d2 *__restrict__ out, size_t rows,
+                                                                size_t row16, int spread, int tiled)
+{
+    const size_t T = blockDim.x;
+    const size_t seg16 = T * U;
+    const size_t nseg = row16 / seg16;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        unsigned h = (unsigned)r * 2654435761u;
+        h ^= h >> 15;
+        const size_t s0 = spread > 1 ? h % (unsigned)spread : 0;
+        auto at = [&](size_t s) { return tiled ? (s * rows + r) * seg16 : r * row16 + s * seg16; };
+        d2 cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = ld<NT>(in + at(s0 % nseg) + threadIdx.x + u * T);
+        for (size_t k = 0; k < nseg; ++k) {
+            const size_t s = (s0 + k) % nseg, sn = (s0 + k + 1) % nseg;
+            const bool more = k + 1 < nseg;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = ld<NT>(in + at(sn) + threadIdx.x + u * T);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) st<NT>(out + at(s) + threadIdx.x + u * T, cur[u]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            }
+        }
+    }
+}
+
 /* rows split in time: piece p of P per row is its own workgroup (no dependency: this is a copy);
  * workgroup id -> (row, piece) with piece-major order, so that concurrently running workgroups
  * touch P windows of the buffer instead of `rows` */
@@ -183,7 +246,49 @@ struct Timer {
 int main(int argc, char **argv)
 {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool tiled_only = argc > 1 && !strcmp(argv[1], "tiled");
     Timer tm;
+    if (tiled_only) {
+        /* round 3: dense rows vs the tiled block layout vs a linear sweep, the same 512 MiB each way, several
+         * passes in one process (the pool's fast/slow state shows as a shift of all three) */
+        const size_t rows = 1024, L = 65536, row16 = L / 2, bytes = rows * L * 8;
+        d2 *in, *out;
+        CHECK(hipMalloc(&in, bytes));
+        CHECK(hipMalloc(&out, bytes));
+        CHECK(hipMemset(in, 0x11, bytes));
+        CHECK(hipMemset(out, 0, bytes));
+        CHECK(hipDeviceSynchronize());
+        size_t fr, tot;
+        CHECK(hipMemGetInfo(&fr, &tot));
+        printf("in %p out %p free %zu MiB of %zu MiB\n", (void *)in, (void *)out, fr >> 20, tot >> 20);
+        auto gbs = [](size_t b, double ms) { return b / ms / 1e6; };
+        for (int pass = 0; pass < 4; ++pass) {
+            double t;
+            t = tm.run([&] { hipLaunchKernelGGL((copy_rows<true, 4>), dim3(rows), dim3(256), 0, 0, in, out, rows, row16, row16); });
+            const double a = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_rows_tiled<true, 4>), dim3(rows), dim3(256), 0, 0, in, out, rows, row16); });
+            const double b = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_rows<true, 8>), dim3(rows), dim3(128), 0, 0, in, out, rows, row16, row16); });
+            const double a2 = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_rows_tiled<true, 8>), dim3(rows), dim3(128), 0, 0, in, out, rows, row16); });
+            const double b2 = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_linear<true, 4>), dim3(2048), dim3(256), 0, 0, in, out, rows * L / 2); });
+            const double c = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_linear<true, 4>), dim3(1024), dim3(256), 0, 0, in, out, rows * L / 2); });
+            const double c2 = gbs(2 * bytes, t);
+            printf("pass %d: dense rows 256xU4 %6.0f | tiled 256xU4 %6.0f | dense rows 128xU8 %6.0f | tiled 128xU8 %6.0f | "
+                   "linear 2048x256 %6.0f | linear 1024x256 %6.0f GB/s\n", pass, a, b, a2, b2, c, c2);
+            fflush(stdout);
+        }
+        for (int spread : {1, 2, 4, 8, 32}) {
+            double t = tm.run([&] { hipLaunchKernelGGL((copy_rows_tiled_desync<true, 4>), dim3(rows), dim3(256), 0, 0, in, out, rows, row16, spread, 1); });
+            const double a = gbs(2 * bytes, t);
+            t = tm.run([&] { hipLaunchKernelGGL((copy_rows_tiled_desync<true, 4>), dim3(rows), dim3(256), 0, 0, in, out, rows, row16, spread, 0); });
+            printf("workgroups out of step by up to %2d segments of 32: tiled %6.0f | dense rows %6.0f GB/s\n", spread, a, gbs(2 * bytes, t));
+            fflush(stdout);
+        }
+        return 0;
+    }
     const size_t maxbytes = (size_t)9 << 30;           /* 9 GiB each: holds 1024 rows at the bench's 8 MiB + 1 KiB pitch */
     d2 *in, *out;
     CHECK(hipMalloc(&in, maxbytes));
