@@ -186,6 +186,10 @@ class FilterBank:
                "RTFilterBank_updaten_chained")
         return ev.value if want_event else None
 
+    def set_pace(self, ns_per_segment):
+        """Schedule of tiled launches: > 0 period per 2048-sample segment in ns, 0 off, < 0 the library's choice."""
+        _check(dspdll.RTFilterBank_set_pace(self._handle, float(ns_per_segment)), "RTFilterBank_set_pace")
+
     def chain_join(self, stream=None):
         """`stream` waits for every chained call so far; the carried state is back in place."""
         _check(dspdll.RTFilterBank_chain_join(self._handle, _stream_ptr(stream, self.device)), "RTFilterBank_chain_join")

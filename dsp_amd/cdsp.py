@@ -178,6 +178,7 @@ _proto("RTFilterBank_updaten_tiled", c_int, [c_void_p, c_void_p, c_void_p, c_siz
 _proto("RTFilterBank_updaten_chained", c_int,
        [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_uint, c_void_p, POINTER(c_void_p)])
 _proto("RTFilterBank_chain_join", c_int, [c_void_p, c_void_p])
+_proto("RTFilterBank_set_pace", c_int, [c_void_p, c_double])
 _proto("dsp_tile_rows", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
 _proto("dsp_untile_rows", c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterBank_updaten_host", c_int, [c_void_p, _dp, c_size_t, _dp, c_size_t, c_size_t])

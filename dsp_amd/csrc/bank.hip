@@ -462,6 +462,8 @@ struct Group {
     double *d_fval = nullptr;
     int32_t *d_init = nullptr;
     bool contiguous = false;
+    double pace_ns = -1.0;              /* paced tiled launches: period per segment set by RTFilterBank_set_pace
+                                           (0 = off, < 0 = the library's choice, pace_period) */
 };
 
 /* RTFilterBank_updaten_chained: two internal streams, a ring of events and the device words of ChainView
@@ -1754,6 +1756,27 @@ int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out,
 
 size_t RTFilterBank_noalloc_max_doubles(void) { return kStaticScratchDoubles; }
 
+/* Period of a paced tiled launch in 1/1024 ticks of 10 ns, 0 = none.  Why: in the tiled layout the workgroups that
+ * run together sweep one contiguous window of HBM per step -- as long as they ARE in step.  Left alone they drift
+ * apart (workgroups on some XCDs run 3-5 % faster) and the lock-step rate of the memory system is lost: the copy
+ * twin falls from 5.9 to 5.5 TB/s when its workgroups are up to 4 segments out of step, to 5.0 without any order
+ * (profiles/r3_tiled_copy.txt); a launch of 256K samples per channel runs 12 % faster on a schedule than without,
+ * one of 64K 4-6 % (profiles/r3_pacing.txt).  The schedule: step `it` not before launch start + it x period, the
+ * period being what one round of segments (32 KiB per workgroup, read + written) takes at the lock-step copy rate.
+ * A period a few per cent too short loses the effect on long launches (every workgroup falls behind and runs
+ * free), one too long costs its excess; the constant below is the rate of a fast-state MI355X of this pool.
+ * Only for groups that fill at least 3/4 of one resident round and launches of 12 segments or more: narrower
+ * banks are not bandwidth-bound (no workgroup is ever early, and the clock reads cost the front wave 0.3 us per
+ * step), shorter launches are mostly pipeline fill. */
+constexpr double kPaceCopyGBs = 5950.0;      /* lock-step 1:1 copy of the tiled layout on MI355X */
+
+unsigned int pace_period(const Group &g, int count, size_t n, int round)
+{
+    if (g.pace_ns == 0.0 || count > round || 4 * count < 3 * round || n / RTFB_TILE < 12) return 0;
+    const double ns = g.pace_ns > 0.0 ? g.pace_ns : (double)count * 32768.0 / kPaceCopyGBs;
+    return (unsigned int)(ns / 10.0 * 1024.0);
+}
+
 /* Shared by _updaten_tiled and _updaten_chained: argument checks, the block's addressing.  tiled: in / out are
  * [n / 2048][nch][2048] (ld ignored). */
 static int pipe_block(const RTFilterBank *bank, double *out, size_t ld_out, const double *in, size_t ld_in, size_t n,
@@ -1797,6 +1820,7 @@ int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in
     if (rc || (rc = chain_close(bank, s))) return rc;
     const GroupView v = view_of(bank, *g);
     const int round = pipe_resident_round();
+    ext.pace_fx = pace_period(*g, v.count, n, round);
     /* a group a little wider than one resident round goes round by round, as in launch_pipe_n */
     const int step = (v.count > round && v.count <= 4 * round) ? round : v.count;
     for (int off = 0; off < v.count; off += step) {
@@ -1884,6 +1908,14 @@ int RTFilterBank_chain_join(RTFilterBank *bank, void *hip_stream)
 {
     if (!bank) return fail(RTFB_EINVAL, "NULL bank");
     return chain_close(bank, static_cast<hipStream_t>(hip_stream));
+}
+
+int RTFilterBank_set_pace(RTFilterBank *bank, double ns_per_segment)
+{
+    if (!bank) return fail(RTFB_EINVAL, "NULL bank");
+    if (ns_per_segment > 1e6) return fail(RTFB_EINVAL, "RTFilterBank_set_pace: period above 1 ms");
+    for (Group &g : bank->groups) g.pace_ns = ns_per_segment;
+    return RTFB_OK;
 }
 
 int dsp_tile_rows(double *tiles, const double *rows, size_t ld, size_t nch, size_t n, void *hip_stream)

@@ -107,6 +107,10 @@ struct PipeExt {
                                               2048 for rows; nch * 2048 in the tiled block layout
                                               [segment][channel][2048] (then BlockIO.ld_* = 2048)                  */
     ChainView chain;                       /* chain.records == nullptr: an ordinary launch                         */
+    /* Paced launch (tiled layout, one resident round): every workgroup holds the prefetch of its step `it` back
+     * until  launch start + it x period  on the chip-wide 100 MHz clock, so that the workgroups of a launch sweep
+     * the tiled block in step (bank.hip: pace_period).  Period in 1/1024 ticks; 0 = not paced. */
+    unsigned int pace_fx;
 };
 
 /* launchers (kernels.hip).  Each returns the hipError_t of the launch. */

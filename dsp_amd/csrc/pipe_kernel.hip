@@ -279,6 +279,12 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
         }
     };
 
+    /* Paced launch (PipeExt.pace_fx): the schedule starts now.  It lives in an LDS word behind the exchange words
+     * (the next due time in 1/1024 ticks), not in scalar registers, which the front wave's table batches need. */
+    const bool paced = kWhole && !kChain && ext.pace_fx != 0;
+    unsigned long long *psch = reinterpret_cast<unsigned long long *>(xch + 2);
+    if (paced && front && lane == 0)
+        psch[0] = (__builtin_amdgcn_s_memrealtime() << 10) + ext.pace_fx;      /* step 1: one period after the start */
     if (front) {
         fetch(0, pre0);
         fetch(1, pre1);
@@ -356,6 +362,12 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             if (it == 0) stamp(7);
             if (it == 8) stamp(12);
             if (it == 9) stamp(23);
+            if (paced && it > 0) {
+                /* the prefetch of step `it` is not issued before  launch start + it x period */
+                const unsigned long long due_fx = psch[0];
+                while (__builtin_amdgcn_s_memrealtime() < (due_fx >> 10)) __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) psch[0] = due_fx + ext.pace_fx;
+            }
             fetch(it + 2, pre);
 
             const bool seeded = seed_stream && it == 0;
@@ -511,6 +523,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             front_step(it, pre0);
             if (it + 1 <= nseg) front_step(it + 1, pre1);
         }
+
     } else {
         /* =============================== BACK ================================ */
         double b[N + 1], a[N + 1];
@@ -755,9 +768,9 @@ static hipError_t launch_pipe_ext(const GroupView &g, const BlockIO &io, const P
         else
             hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, true>), dim3(g.count), dim3(2 * kWave), ldc, s, g, io, ext);
     } else if (g.unit_a0)
-        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, false>), dim3(g.count), dim3(2 * kWave), lds + 32, s, g, io, ext);
     else
-        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, false>), dim3(g.count), dim3(2 * kWave), lds, s, g, io, ext);
+        hipLaunchKernelGGL((iir_pipe_kernel<N, false, true, false>), dim3(g.count), dim3(2 * kWave), lds + 32, s, g, io, ext);
     return hipGetLastError();
 }
 

@@ -156,6 +156,12 @@ EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
  * Other banks: RTFB_EUNSUPPORTED. */
 #define RTFB_TILE 2048
 EXPORT int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream);
+/* The tiled layout pays while the workgroups of a launch stay in step, so tiled launches of banks that fill the GPU
+ * (512 .. 1024 channels on MI355X) run on a schedule: no workgroup requests segment k + 2 of its channel earlier
+ * than launch start + k x period on the chip-wide 100 MHz clock.  A performance hint only -- results do not depend
+ * on it.  The library picks the period (the time one round of segments takes at the lock-step copy rate);
+ * ns_per_segment > 0 sets it, 0 switches pacing off, < 0 returns to the library's choice. */
+EXPORT int RTFilterBank_set_pace(RTFilterBank *bank, double ns_per_segment);
 EXPORT int dsp_tile_rows(double *tiles, const double *rows, size_t ld, size_t nch, size_t n, void *hip_stream);
 EXPORT int dsp_untile_rows(double *rows, size_t ld, const double *tiles, size_t nch, size_t n, void *hip_stream);
 
