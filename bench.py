@@ -411,6 +411,14 @@ def main():
             a5 = copy.copy(args)
             a5.steps, a5.warmup, a5.no_cpu = 8, 2, True
             other["config5_stream16"] = _compact(main_stream16(a5, emit=False))
+            torch.cuda.empty_cache()
+            # config 4, compact: ONE IIR-8 wave and ONE FIR-32 wave of 65 536 channels x 64K (the two kinds of wave
+            # the 2^20-channel bank consists of), alternating
+            a4 = copy.copy(args)
+            a4.steps, a4.warmup, a4.no_cpu = 6, 2, True
+            a4.mixed_total, a4.mixed_channels, a4.mixed_layout = 2 * 65536, 65536, "sorted"
+            a4.gather = a4.gather_fval = False
+            other["config4_mixed"] = _compact(main_mixed(a4, emit=False))
             line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -512,7 +520,7 @@ def main_fir512(args, emit=True):
         dist.destroy_process_group()
 
 
-def main_mixed(args):
+def main_mixed(args, emit=True):
     """BASELINE.json config 4 as SURVEY.md 8(d) pins it: a 2^20-channel bank, channels sorted by type -- the
     first 2^19 are the 8th-order IIR of config 2, the next 2^19 a 32-tap windowed-sinc FIR -- x 65 536 samples,
     contiguous channel ranges of 2^20/N per GPU, processed in WAVES of 2^16 channels (32 GiB in + 32 GiB out:
@@ -695,6 +703,10 @@ def main_mixed(args):
                 "xgmi_gbs_per_rank": recv / (float(np.mean(g_ms)) / 1e3) / 1e9 if world > 1 else None,
                 "xgmi_gbs_per_link": recv / (float(np.mean(g_ms)) / 1e3) / 1e9 / 7 if world > 1 else None,
             }
+        if not emit:
+            for bk in banks:
+                bk.close()
+            return line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -451,7 +451,8 @@ struct Group {
     int32_t *d_chan = nullptr;
     int32_t *d_design = nullptr;
     double *d_state = nullptr;
-    double *d_state_alt = nullptr;      /* FIR: other half of the state ping-pong */
+    double *d_state_alt = nullptr;      /* FIR: where the end-state kernels build the next state before it is
+                                           committed to d_state (never holds state between calls) */
     int32_t *d_aux = nullptr;           /* FIR: prologue -> main/epilogue hand-off */
     int kmax = 0;                       /* FIR: longest filter in the group        */
     bool has_partial = false;           /* FIR: a partial_init design is present    */
@@ -1712,8 +1713,7 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
                 fio.ld_in = n;
             }
             v.fir_mfma = (bank->mode != RTFB_MODE_SEQUENTIAL && g.kmax >= kFirMfmaMinTaps) ? 1 : 0;
-            HIP_TRY(launch_fir(v, fio, s));
-            if (fir_uses_state_swap(v, fio)) std::swap(g.d_state, g.d_state_alt);
+            HIP_TRY(launch_fir(v, fio, s));      /* leaves the end state in g.d_state (d_state_alt is scratch) */
             continue;
         }
         if (g.cls == kIirGeneric) {

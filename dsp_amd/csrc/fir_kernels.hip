@@ -1164,6 +1164,26 @@ static hipError_t launch_fir_seq(const GroupView &g, const BlockIO &io, hipStrea
     return hipGetLastError();
 }
 
+/* The end-state kernels write the block's end state into g.state_out (their workgroups read g.state while others
+ * already write); this puts it back into g.state, so that every call leaves the carried delay line in ONE fixed
+ * buffer and a captured call can be replayed any number of times (round 2 swapped the two buffers on the host,
+ * which a graph replay cannot see).  16 B per channel and tap: 0.1 ms of a 65 ms step at 65 536 x 512 taps. */
+__global__ void __launch_bounds__(256) fir_commit_kernel(GroupView g)
+{
+    const size_t total = (size_t)g.count * g.state_ld;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
+        g.state[i] = g.state_out[i];
+}
+
+static hipError_t launch_fir_commit(const GroupView &g, hipStream_t s)
+{
+    const size_t total = (size_t)g.count * g.state_ld;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fir_commit_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
 bool fir_uses_state_swap(const GroupView &g, const BlockIO &io)
 {
     /* mixed designs keep their taps in vector registers: that fits up to 16 slots */
@@ -1273,11 +1293,13 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
         const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
         const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
         hipLaunchKernelGGL(fir_epilogue_taps_kernel, dim3(passes, g.count), dim3(kWave), lds_taps, s, g, io);
-        return hipGetLastError();
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return launch_fir_commit(g, s);
     }
     const size_t epi_lds = (size_t)(g.kmax + (g.kmax + kEpiR) + (g.kmax + kEpiR) / kEpiR + 2) * sizeof(double);
     hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(kEpiThreads), epi_lds, s, g, io);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_fir_commit(g, s);
 }
 
 }  // namespace dsp

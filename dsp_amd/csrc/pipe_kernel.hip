@@ -263,13 +263,15 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
     };
     /* kWhole: piece i of a prefetched segment has arrived once at most (newer + 15 - i) loads are outstanding,
      * `newer` = loads issued after that segment's.  The wait clobbers "memory", so the tile write that follows
-     * it (a memory operation) cannot be scheduled above it; the loaded registers themselves must not be read
-     * in between -- nothing does, and the listing is the check (no copy of them before the wait). */
-    auto park_wait = [&](int i, bool newer_in_flight) {
+     * it (a memory operation) cannot be scheduled above it, and it names the loaded register as an in/out
+     * operand: whatever reads that register afterwards reads the wait's output, so no read or copy of it can be
+     * scheduled above the wait (a copy made BEFORE the wait would have to feed the wait's operand -- the compiler
+     * has no reason to make one, and the listing shows none). */
+    auto park_wait = [&](int i, bool newer_in_flight, d2 &reg) {
         if constexpr (kWhole) {
             const int cnt = (newer_in_flight ? kNewerInFlight : 0) + kPPieces - 1 - i;
             switch (cnt) {
-#define DSP_PW(C) case C: asm volatile("s_waitcnt vmcnt(" #C ")" ::: "memory"); break;
+#define DSP_PW(C) case C: asm volatile("s_waitcnt vmcnt(" #C ")" : "+v"(reg) : : "memory"); break;
                 DSP_PW(0) DSP_PW(1) DSP_PW(2) DSP_PW(3) DSP_PW(4) DSP_PW(5) DSP_PW(6) DSP_PW(7)
                 DSP_PW(8) DSP_PW(9) DSP_PW(10) DSP_PW(11) DSP_PW(12) DSP_PW(13) DSP_PW(14) DSP_PW(15)
                 DSP_PW(16) DSP_PW(17) DSP_PW(18) DSP_PW(19) DSP_PW(20) DSP_PW(21) DSP_PW(22) DSP_PW(23)
@@ -343,13 +345,13 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
                 if (it + 1 < nseg) {                          /* segment it+1's loads are younger, still flying */
 #pragma unroll
                     for (int i = 0; i < kPPieces; ++i) {
-                        park_wait(i, true);
+                        park_wait(i, true, pre[i]);
                         *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < kPPieces; ++i) {
-                        park_wait(i, false);
+                        park_wait(i, false, pre[i]);
                         *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
                     }
                 }

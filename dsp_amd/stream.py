@@ -200,7 +200,9 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None, total
              vector of its own chunk from its last M samples; ONE all_gather (2 x pack_len doubles per rank: that
              vector and the rank's state at entry) moves everything; all ranks filter concurrently.
       exact  no usable decay: chunk maps are composed (RTFilterStream.h): ranks >= 1 run their chunk from the zero
-             state first, one all_gather, compose, run again (2 passes on ranks >= 1; exact, no truncation).
+             state first, one all_gather, compose, run again (2 passes on ranks >= 1; exact, no truncation).  An
+             in-place call (out_local overlapping x_local) is allowed: the first pass then writes to a scratch
+             chunk kept with the plan.
       chain  engines that can do neither (FIR, designs off the scan path): rank r waits for rank r-1's true end
              state (send/recv); exact and serial.
     """
@@ -225,18 +227,36 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None, total
     def peer(r):
         return dist.get_global_rank(group, r) if group is not None else r
 
+    # Hand-off buffers are allocated ONCE per (engine, plan) and reused: at 8 GPUs a config-5 step is ~0.45 ms of
+    # kernel time, so per-call tensor allocation and torch.stack traffic would sit on the critical path.
+    bufs = engine.__dict__.setdefault("_split_bufs", {})
+    bkey = (x_local.numel(), world, rank, mode)
+    if bkey not in bufs:
+        proto = engine.new_pack()
+        plen = proto.numel()
+        rows = 2 if mode == "tail" else 1
+        bufs[bkey] = dict(mine=torch.zeros((rows, plen), dtype=torch.float64, device=proto.device),
+                          everyone=torch.zeros((world, rows, plen), dtype=torch.float64, device=proto.device),
+                          scratch=None)
+    buf = bufs[bkey]
+
     def gather(mine):
-        """(world, *mine.shape) tensor on mine's device"""
-        m = wire(mine.contiguous())
-        parts = [torch.empty_like(m) for _ in range(world)]
-        dist.all_gather(parts, m, group=group)
-        return torch.stack(parts).to(mine.device)
+        """all ranks' `mine` in buf["everyone"] (world, rows, plen), on mine's device; no allocation under RCCL"""
+        every = buf["everyone"]
+        if host_hop:
+            m = wire(mine)
+            parts = [torch.empty_like(m) for _ in range(world)]
+            dist.all_gather(parts, m, group=group)
+            for r, part in enumerate(parts):
+                every[r].copy_(part)
+        else:
+            dist.all_gather_into_tensor(every, mine, group=group)
+        return every
 
     carried_remote = bool(engine.__dict__.get("_carry_on_last_rank", False))
-    plen = engine.new_pack().numel()
     with ctx:
         if mode == "tail":
-            pack2 = torch.zeros((2, plen), dtype=torch.float64, device=engine.new_pack().device)
+            pack2 = buf["mine"]                                     # [0]: hand-off of my chunk (stays zero on the last rank)
             engine.export_state(pack2[1], stream)                   # my state at entry (the last rank's matters)
             if rank < world - 1:
                 ok = engine.tail_state(x_local, pack2[0], stream)
@@ -249,7 +269,7 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None, total
                 engine.import_state(everyone[rank - 1, 0], stream)
             out = engine(x_local, out_local, stream)
         elif mode == "exact":
-            pack = engine.new_pack()
+            pack = buf["mine"][0]
             if carried_remote:                                      # rank 0 needs its start state before its pass
                 engine.export_state(pack, stream)
                 last = wire(pack)
@@ -260,18 +280,28 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None, total
                 out = engine(x_local, out_local, stream)            # true pass; the vector is the true end state
                 engine.export_state(pack, stream)
             elif rank < world - 1:
+                # Zero-state pass: only its end state v_r is wanted.  Its outputs must NOT land on the inputs (an
+                # in-place call: out_local is x_local, or the two overlap), which the true pass below reads again:
+                # they go to a scratch chunk kept with the plan in that case.
+                first_out = out_local
+                if out_local is not None and _overlap(out_local, x_local):
+                    if buf["scratch"] is None or buf["scratch"].numel() < x_local.numel():
+                        buf["scratch"] = torch.empty(x_local.numel(), dtype=x_local.dtype, device=x_local.device)
+                    first_out = buf["scratch"][: x_local.numel()].view(x_local.shape)
                 engine.zero_state(stream)
-                out = engine(x_local, out_local, stream)            # zero-state pass: its end state is v_r
+                out = engine(x_local, first_out, stream)
                 engine.export_state(pack, stream)
+                if first_out is not out_local:
+                    out = out_local
             else:
                 out = out_local
                 pack.zero_()
-            everyone = gather(pack)
+            everyone = gather(buf["mine"])[:, 0]
             if rank > 0:
                 engine.compose_state(everyone, rank, lens[1], stream)
                 out = engine(x_local, out, stream)
         else:
-            pack = engine.new_pack()
+            pack = buf["mine"][0]
             if carried_remote:
                 engine.export_state(pack, stream)
                 last = wire(pack)
@@ -288,6 +318,14 @@ def split_update(engine, x_local, out_local=None, group=None, stream=None, total
                 dist.send(wire(pack), dst=peer(rank + 1), group=group)
     engine.__dict__["_carry_on_last_rank"] = True
     return out
+
+
+def _overlap(p, q):
+    """True if two tensors share memory (same storage range)."""
+    if p.device != q.device or p.numel() == 0 or q.numel() == 0:
+        return False
+    p0, q0 = p.data_ptr(), q.data_ptr()
+    return p0 < q0 + q.numel() * q.element_size() and q0 < p0 + p.numel() * p.element_size()
 
 
 def sync_end_state(engine, group=None, stream=None):

@@ -134,10 +134,9 @@ EXPORT int RTFilterBank_updaten(RTFilterBank *bank, double *out, size_t ld_out,
  * 32 MiB, held by every GPU the library runs on until the process ends), else RTFB_ESIZE.  Every call on a GPU shares that
  * GPU's array: calls that overlap in time on one GPU (different streams or threads) race on it; calls on one
  * stream are ordered.  Calls that are not in place, or touch no FIR channel, need no staging and have no size
- * limit.  Capturing is one thing, REPLAYING a captured call another: IIR channels keep their state in place, so a
- * replayed call continues the stream; FIR channels (time-split kernels) alternate between two state buffers from
- * call to call, and that alternation happens on the host -- a graph that holds ONE call of a bank with FIR channels
- * must not be replayed (capture an even number of consecutive calls, or call directly). */
+ * limit.  A captured call may be REPLAYED any number of times: every call, IIR or FIR, leaves the carried state in
+ * the one buffer the next call reads (the FIR end-state kernels build it in a second buffer and commit it at the
+ * end of the call), so each replay continues the stream by one block. */
 EXPORT int RTFilterBank_updaten_noalloc(RTFilterBank *bank, double *out, size_t ld_out,
                                         const double *in, size_t ld_in, size_t n, void *hip_stream);
 EXPORT size_t RTFilterBank_noalloc_max_doubles(void);

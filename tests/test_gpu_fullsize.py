@@ -252,3 +252,41 @@ def test_config2_every_channel_every_sample_vs_oracle(G):
         err = util.rel_to_peak(ys["scan"][c0:c0 + step].cpu().numpy(), want)
         worst = max(worst, float(err.max()))
     assert worst <= TOL, worst
+
+
+def test_config4_benchmarked_wave_shape_both_kinds(G):
+    """Config 4 as bench.py times it: sorted waves of 65 536 channels x 65 536 samples at row pitch 64K + 128
+    (32 GiB each way, row offsets beyond 2^32 bytes) -- one wave of the order-8 IIR (the pipelined kernel 64 resident
+    rounds deep) and one of the 32-tap FIR (matrix-core kernel).  AUTO against the bit-exact mode on every channel
+    and sample, and both against the oracle on channels 0, 32 767 and 65 535."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    C_, B = 1 << 16, 1 << 16
+    pitch = B + 128
+    xb = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+    x = xb[:, :B]
+    gbank.synth_fill(x, 0x5EED0004)
+    for key in ("bw4_bp_0.3_0.6", "fir32_lp_0.25"):
+        d = G.golden_design(key)
+        ys = {}
+        for name, mode in (("auto", gbank.MODE_AUTO), ("exact", gbank.MODE_SEQUENTIAL)):
+            bank = gbank.FilterBank([d], [0] * C_, mode=mode)
+            yb = torch.empty((C_, pitch), dtype=torch.float64, device="cuda")
+            bank.updaten_ptr(yb.data_ptr(), pitch, x.data_ptr(), pitch, B)
+            torch.cuda.synchronize()
+            ys[name] = (yb[:, :B], bank.get_state())
+            bank.close()
+        worst = 0.0
+        for c0 in range(0, C_, 8192):
+            worst = max(worst, _rel_to_peak_dev(ys["auto"][0][c0:c0 + 8192], ys["exact"][0][c0:c0 + 8192]))
+        assert worst <= TOL, (key, worst)
+        st_a, st_e = ys["auto"][1][0], ys["exact"][1][0]
+        assert np.max(np.abs(st_a - st_e)) <= TOL * max(1.0, np.max(np.abs(st_e))), key
+        od = G.to_orc_design(d)
+        for c in (0, C_ // 2 - 1, C_ - 1):
+            want = orc.Filter(od["kind"], od["b"], od.get("a"), od["init_mode"]).updaten(util.synth(0x5EED0004, c, 0, B))
+            assert util.bits_equal(ys["exact"][0][c].cpu().numpy(), want), (key, c)
+            got = ys["auto"][0][c].cpu().numpy()
+            assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), (key, c)
+        del ys

@@ -59,8 +59,7 @@ def test_block_updates_replayed_from_a_graph(G, case):
 @pytest.mark.parametrize("case", ["iir-scan", "fir-mfma", "fir-exact"])
 def test_a_graph_of_two_calls_replayed_twice_continues_the_streams(G, case):
     """Replaying the same graph again feeds the same input blocks to the running streams: IIR state is updated in
-    place, the time-split FIR kernels alternate two state buffers per call (so an EVEN number of captured calls
-    lands where it started: include/RTFilterBank.h)."""
+    place, and every FIR call commits its end state to the one buffer the next call reads."""
     import torch
     from dsp_amd import bank as gbank
     from oracle import oracle as orc
@@ -99,4 +98,54 @@ def test_a_graph_of_two_calls_replayed_twice_continues_the_streams(G, case):
         assert np.max(np.abs(st[:, :w] - ob.state)) <= 1e-12 * max(1.0, float(np.max(np.abs(ob.state))))
     else:
         assert util.bits_equal(st[:, :w], ob.state)
+    gb.close()
+
+
+@pytest.mark.parametrize("case", ["iir-scan", "fir-mfma", "fir-exact", "fir-partial"])
+def test_a_graph_of_one_call_replayed_three_times(G, case):
+    """ONE captured call replayed three times continues the stream three blocks (round 2 kept the parity of the FIR
+    state's two buffers on the host, where a replay cannot see it: an odd number of captured calls corrupted the
+    carried delay line).  Outputs of every replay and the final state against the oracle."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    if case == "iir-scan":
+        designs, mode = [G.golden_design("bw4_bp_0.3_0.6")], gbank.MODE_SCAN
+    elif case == "fir-partial":
+        designs, mode = [G.golden_design("mavg32"), G.golden_design("fir7_lp_0.4")], gbank.MODE_AUTO
+    else:
+        designs = [G.golden_design("fir32_lp_0.25"), G.golden_design("fir7_lp_0.4")]
+        mode = gbank.MODE_SEQUENTIAL if case == "fir-exact" else gbank.MODE_AUTO
+    nch, n = 48, 8192
+    idx = [c % len(designs) for c in range(nch)]
+    gb = gbank.FilterBank(designs, idx, mode=mode)
+    ob = orc.Bank([G.to_orc_design(d) for d in designs], idx)
+    x = G.make_inputs(29, nch, 2 * n)
+    xd = G.to_dev(x)
+    yd = torch.zeros_like(xd)
+    ld = 2 * n
+    gb.updaten_ptr(yd.data_ptr(), ld, xd.data_ptr(), ld, n)            # block 0 outside the graph (initialisers)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        gb.updaten_ptr(yd.data_ptr() + n * 8, ld, xd.data_ptr() + n * 8, ld, n, torch.cuda.current_stream())
+    ob.updaten(x[:, :n].copy(), threads=4)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ob.updaten(x[:, n:].copy(), threads=4)                  # the same block again, stream running on
+        got = yd[:, n:].cpu().numpy()
+        if case == "fir-exact":
+            assert util.bits_equal(got, want)
+        else:
+            assert np.all(util.rel_to_peak(got, want) <= 1e-12)
+    st, fv, ini = gb.get_state()
+    w = ob.state.shape[1]
+    if case == "iir-scan":
+        assert np.max(np.abs(st[:, :w] - ob.state)) <= 1e-12 * max(1.0, float(np.max(np.abs(ob.state))))
+    else:
+        for c in range(nch):
+            k = len(designs[idx[c]]["b"])
+            assert util.bits_equal(st[c, :k], ob.state[c, :k]), c
     gb.close()

@@ -219,7 +219,9 @@ def _rank_worker(rank, world, port, n, q, design="bw8"):
         for blk in range(2):
             lo, hi = gstream.time_range(n, world, rank)
             x = torch.from_numpy(util.synth(21, 0, blk * n + lo, hi - lo)).cuda()
-            y = gstream.split_update(fs, x, total=n if blk else None)    # with and without the static plan
+            # with and without the static plan; the second block IN PLACE (in the composed-maps mode the middle
+            # ranks run two passes over x: the first must not overwrite it)
+            y = gstream.split_update(fs, x, x if blk else None, total=n if blk else None)
             torch.cuda.synchronize()
             parts = [None] * world
             dist.all_gather_object(parts, y.cpu().numpy())
