@@ -424,7 +424,10 @@ struct Design {
     int gtab1_off = 0;
     double scan_error = HUGE_VAL;       /* conditioning probe result (fast IIR designs) */
     bool has_tables = false;            /* scan tables built (false: the design's group is sequential-only) */
-    std::vector<int> section_design;    /* RTFB_KIND_SOS: the IIR design (nb = na = 3) of every section */
+    std::vector<int> section_design;    /* RTFB_KIND_SOS, not fused: the IIR design (nb = na = 3) of every section */
+    bool sos_fused = false;             /* RTFB_KIND_SOS with <= kMaxFusedSections sections, every a0 == 1: all sections
+                                           per sample in ONE pass (2 states per section on the pipelined kernel, or the
+                                           lane-per-channel kernel); other cascades run one pass per section */
     bool scan_safe() const;
     /* SOS: three slots per section, laid out section after section (the third, never written, is 0) */
     int state_slots() const { return kind == RTFB_KIND_IIR ? std::max(nb, na) : nb; }
@@ -432,6 +435,9 @@ struct Design {
     {
         return kind == RTFB_KIND_IIR && nb == na && nb >= 2 && nb - 1 <= kMaxFastOrder;
     }
+    bool fast() const { return fast_iir() || sos_fused; }
+    /* states of the system the fast kernels run: the filter order, or two per fused section */
+    int fast_n() const { return sos_fused ? 2 * (nb / 3) : nb - 1; }
 };
 
 enum GroupClass { kIirFast = 0, kIirGeneric = 1, kFir = 2 };
@@ -442,6 +448,7 @@ struct Group {
     bool scan_safe = false;             /* kIirFast: every design passed the conditioning probe */
     bool has_tables = true;             /* kIirFast: every design carries its scan tables          */
     bool unit_a0 = false;               /* kIirFast: every design has a[0] == 1.0               */
+    int sos_sections = 0;               /* kIirFast: > 0 = fused cascades of this many sections (order = 2 x that) */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
     std::vector<int32_t> chan_design;   /* design index per entry of chans (a section's design for SOS channels) */
     int stage = 0;                      /* SOS: which section of its channels this group runs; stage k reads the
@@ -604,6 +611,101 @@ void pipe_ttable(const Design &d, int T, std::vector<double> &out)
     }
 }
 
+/* ---- fused second-order sections: the cascade as one linear system ---------------------------------------------
+ * z = (s^1_0, s^1_1, s^2_0, s^2_1, ...), z' = A z + B x with A block lower-triangular: section k sees the output
+ * of section k-1 within the same sample.  A and B are read off one step of the cascade in long double (columns of
+ * A: the step from a unit state with x = 0; B: the step from the zero state with x = 1). */
+struct LinSys {
+    int N = 0;
+    std::vector<long double> A, B;
+};
+
+LinSys sos_system(const Design &d)
+{
+    const int S = d.nb / 3, N = 2 * S;
+    LinSys sys;
+    sys.N = N;
+    sys.A.assign((size_t)N * N, 0.0L);
+    sys.B.assign(N, 0.0L);
+    auto step = [&](std::vector<long double> z, long double x) {
+        for (int k = 0; k < S; ++k) {
+            const long double b0 = d.b[3 * k], b1 = d.b[3 * k + 1], b2 = d.b[3 * k + 2];
+            const long double a0 = d.a[3 * k], a1 = d.a[3 * k + 1], a2 = d.a[3 * k + 2];
+            const long double y = (b0 * x + z[2 * k]) / a0;
+            z[2 * k] = z[2 * k + 1] + (b1 * x - a1 * y);
+            z[2 * k + 1] = b2 * x - a2 * y;
+            x = y;
+        }
+        return z;
+    };
+    for (int j = 0; j < N; ++j) {
+        std::vector<long double> e(N, 0.0L);
+        e[j] = 1.0L;
+        const std::vector<long double> col = step(e, 0.0L);
+        for (int i = 0; i < N; ++i) sys.A[(size_t)i * N + j] = col[i];
+    }
+    sys.B = step(std::vector<long double>(N, 0.0L), 1.0L);
+    return sys;
+}
+
+std::vector<long double> sys_mul(int N, const std::vector<long double> &p, const std::vector<long double> &q)
+{
+    std::vector<long double> r((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; ++i)
+        for (int k = 0; k < N; ++k) {
+            const long double pik = p[(size_t)i * N + k];
+            if (pik == 0.0L) continue;
+            for (int j = 0; j < N; ++j) r[(size_t)i * N + j] += pik * q[(size_t)k * N + j];
+        }
+    return r;
+}
+
+/* A^(T 2^k), k < levels (as scan_powers) */
+void sys_powers(const LinSys &sys, int T, int levels, std::vector<double> &out)
+{
+    std::vector<long double> P = sys.A;
+    for (int t = 1; t < T; t <<= 1) P = sys_mul(sys.N, P, P);
+    for (int lvl = 0; lvl < levels; ++lvl) {
+        for (long double v : P) out.push_back((double)v);
+        P = sys_mul(sys.N, P, P);
+    }
+}
+
+/* G[n][i] = (A^(T-1-n) B)_i, n < T, then N zeros where a transfer-function design keeps the response to its
+ * never-written tail slot (a cascade has none) -- the layout of scan2_gtable */
+void sys_gtable(const LinSys &sys, int T, std::vector<double> &out)
+{
+    const int N = sys.N;
+    std::vector<long double> w = sys.B, t(N);
+    std::vector<double> table((size_t)T * N);
+    for (int n = T - 1; n >= 0; --n) {
+        for (int i = 0; i < N; ++i) table[(size_t)n * N + i] = (double)w[i];
+        for (int i = 0; i < N; ++i) {
+            long double acc = 0.0L;
+            for (int j = 0; j < N; ++j) acc += sys.A[(size_t)i * N + j] * w[j];
+            t[i] = acc;
+        }
+        w = t;
+    }
+    out.insert(out.end(), table.begin(), table.end());
+    out.insert(out.end(), (size_t)N, 0.0);
+}
+
+/* row propagators A^(T j), j < 64, stored [e][j] (as pipe_ttable) */
+void sys_ttable(const LinSys &sys, int T, std::vector<double> &out)
+{
+    const int N = sys.N;
+    std::vector<long double> AT = sys.A, P((size_t)N * N, 0.0L);
+    for (int t = 1; t < T; t <<= 1) AT = sys_mul(N, AT, AT);
+    for (int i = 0; i < N; ++i) P[(size_t)i * N + i] = 1.0L;
+    const size_t base = out.size();
+    out.resize(base + (size_t)kWave * N * N);
+    for (int j = 0; j < kWave; ++j) {
+        for (size_t e = 0; e < P.size(); ++e) out[base + e * kWave + j] = (double)P[e];
+        P = sys_mul(N, AT, P);
+    }
+}
+
 /* Combine levels of the two-wave scan kernel that still matter for a design:
  * level k applies A^(32*2^k); once every entry of that power (and of all
  * higher ones) is below 2^-75 its contribution is more than 2^-20 below one ulp
@@ -666,7 +768,8 @@ static inline __attribute__((always_inline)) double scan_probe_body(const Design
                                                                     const double *pw, int nlev, const double *gtab,
                                                                     const double *ttab)
 {
-    const int N = NN ? NN : d.nb - 1, T = pk.T, R = pk.R, L = 2 * R * T, S = N + 1;
+    const int N = NN ? NN : d.fast_n(), T = pk.T, R = pk.R, L = 2 * R * T, S = N + 1;
+    const bool sos = d.sos_fused;       /* cascade: reference = the sections one after the other per sample */
     std::vector<double> x(L), yref(L), y(L);
     uint64_t z = 0x243F6A8885A308D3ull;
     for (int k = 0; k < L; ++k) {                /* splitmix64 stream in [-1, 1) */
@@ -679,7 +782,26 @@ static inline __attribute__((always_inline)) double scan_probe_body(const Design
     }
     const double *b = d.b.data(), *a = d.a.data();
     const bool unit = a[0] == 1.0;
-    {
+    if (sos) {
+        const int nsec = N / 2;
+        std::vector<double> s3(3 * nsec, 0.0);   /* reference order per section, as sos_step_ref */
+        for (int k = 0; k < L; ++k) {
+            double xv = x[k];
+            for (int q = 0; q < nsec; ++q) {
+                double t = xv * b[3 * q];
+                t = t + s3[3 * q];
+                const double yv = a[3 * q] == 1.0 ? t : t / a[3 * q];
+                double u = 0.0 + b[3 * q + 1] * xv;
+                u = u - a[3 * q + 1] * yv;
+                s3[3 * q] = s3[3 * q + 1] + u;
+                u = 0.0 + b[3 * q + 2] * xv;
+                u = u - a[3 * q + 2] * yv;
+                s3[3 * q + 1] = s3[3 * q + 2] + u;
+                xv = yv;
+            }
+            yref[k] = xv;
+        }
+    } else {
         std::vector<double> s(S, 0.0);           /* reference order, as iir_step_ref */
         for (int k = 0; k < L; ++k) {
             double t = x[k] * b[0];
@@ -739,7 +861,18 @@ static inline __attribute__((always_inline)) double scan_probe_body(const Design
                 for (int i = 0; i < N; ++i) s[i] = j ? v[(size_t)(j - 1) * N + i] : carry[i];
             }
             s[N] = carry[N];
-            for (int k = 0; k < T; ++k) {        /* as iir_step_fused */
+            for (int k = 0; k < T && sos; ++k) {  /* as sos_step_fused */
+                double xv = xs[j * T + k];
+                for (int q = 0; q < N / 2; ++q) {
+                    double yv = __builtin_fma(xv, b[3 * q], s[2 * q]);
+                    if (a[3 * q] != 1.0) yv = yv / a[3 * q];
+                    s[2 * q] = __builtin_fma(-a[3 * q + 1], yv, __builtin_fma(b[3 * q + 1], xv, s[2 * q + 1]));
+                    s[2 * q + 1] = __builtin_fma(-a[3 * q + 2], yv, b[3 * q + 2] * xv);
+                    xv = yv;
+                }
+                ys[j * T + k] = xv;
+            }
+            for (int k = 0; k < T && !sos; ++k) {        /* as iir_step_fused */
                 const double xv = xs[j * T + k];
                 double yv = __builtin_fma(xv, b[0], s[0]);
                 if (!unit) yv = yv / a[0];
@@ -768,7 +901,7 @@ static inline __attribute__((always_inline)) double scan_probe_by_order(const De
                                                                         const double *pw, int nlev, const double *gtab,
                                                                         const double *ttab)
 {
-    switch (d.nb - 1) {
+    switch (d.fast_n()) {
         case 2: return scan_probe_body<kHw, 2>(d, pk, pw, nlev, gtab, ttab);
         case 4: return scan_probe_body<kHw, 4>(d, pk, pw, nlev, gtab, ttab);
         case 6: return scan_probe_body<kHw, 6>(d, pk, pw, nlev, gtab, ttab);
@@ -815,8 +948,24 @@ struct DesignTables {
 DesignTables build_design_tables(const Design &d, bool with_ttab, const ProbeKernel &pk, std::vector<double> &mine)
 {
     DesignTables t;
-    const int N = d.nb - 1;
     mine.clear();
+    if (d.sos_fused) {
+        /* fused cascade: only the pipelined kernel's tables (layout: A^(32 2^k) | G32 | row propagators) */
+        const LinSys sys = sos_system(d);
+        t.pow2 = 0;
+        sys_powers(sys, kScan2T, kScan2Levels, mine);
+        t.levels2 = scan2_levels(mine.data(), sys.N);
+        t.gtab = mine.size();
+        sys_gtable(sys, kScan2T, mine);
+        if (with_ttab) {
+            t.ttab = mine.size();
+            sys_ttable(sys, kScan2T, mine);
+            t.scan_error = scan_probe(d, kProbePipe, &mine[t.pow2], std::min(t.levels2, kScanLevels), &mine[t.gtab],
+                                      &mine[t.ttab]);
+        }
+        return t;
+    }
+    const int N = d.nb - 1;
     /* A^(64 2^k), k < 6, are levels 1..6 of A^(32 2^k), k < 7 (same squarings, same bits): one chain serves both */
     static_assert(kScanT == 2 * kScan2T && kScan2Levels == kScanLevels + 1, "the two power tables share a chain");
     std::vector<double> chain;
@@ -879,6 +1028,10 @@ constexpr size_t kSeqOnlyChannels = 2 * kAutoSeqMinChannels;   /* orders <= 8: s
 size_t design_table_doubles(const Design &d, bool with_ttab)
 {
     if (!d.has_tables) return 0;
+    if (d.sos_fused) {
+        const size_t N = (size_t)d.fast_n();
+        return (size_t)kScan2Levels * N * N + ((size_t)kScan2T + 1) * N + (with_ttab ? (size_t)kWave * N * N : 0);
+    }
     const size_t N = (size_t)d.nb - 1;
     size_t n = (size_t)kScanLevels * N * N + ((size_t)kScanT + 1) * N + (size_t)kScan2Levels * N * N +
                ((size_t)kScan2T + 1) * N;
@@ -909,8 +1062,18 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
      * kernels run; the channel's sections are chained through launch groups of increasing `stage`. */
     {
         const size_t nd0 = bk->designs.size();
+        /* Cascades of up to kMaxFusedSections sections with a0 == 1 everywhere are FUSED: one launch group, all
+         * sections per sample, one pass over the block (needs the pipelined kernel's per-design row propagators:
+         * banks of <= kMaxPipeDesigns designs).  The others keep one pass per section. */
         for (size_t i = 0; i < nd0; ++i) {
-            if (bk->designs[i].kind != RTFB_KIND_SOS) continue;
+            Design &d = bk->designs[i];
+            if (d.kind != RTFB_KIND_SOS) continue;
+            bool unit = true;
+            for (int k = 0; k < d.nb / 3; ++k) unit = unit && d.a[3 * k] == 1.0;
+            d.sos_fused = unit && d.nb / 3 <= kMaxFusedSections && nd0 <= kMaxPipeDesigns;
+        }
+        for (size_t i = 0; i < nd0; ++i) {
+            if (bk->designs[i].kind != RTFB_KIND_SOS || bk->designs[i].sos_fused) continue;
             const int nsec = bk->designs[i].nb / 3;
             for (int k = 0; k < nsec; ++k) {
                 Design sec;
@@ -924,31 +1087,34 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         }
     }
     /* (channel, stage) -> the design a launch group runs there */
+    auto staged = [](const Design &d) { return d.kind == RTFB_KIND_SOS && !d.sos_fused; };
     auto stages_of = [&](size_t c) { const Design &d = bk->designs[bk->design_of[c]];
-                                     return d.kind == RTFB_KIND_SOS ? (int)d.section_design.size() : 1; };
+                                     return staged(d) ? (int)d.section_design.size() : 1; };
     auto stage_design = [&](size_t c, int stage) { const Design &d = bk->designs[bk->design_of[c]];
-                                                   return d.kind == RTFB_KIND_SOS ? d.section_design[stage] : bk->design_of[c]; };
+                                                   return staged(d) ? d.section_design[stage] : bk->design_of[c]; };
     {
         /* Designs whose launch group can never take a scan kernel carry no scan tables and skip the
          * conditioning probe: orders <= 8 in a class of >= 2 * kAutoSeqMinChannels channels run the
          * lane-per-channel kernel in every mode (RTFilterBank_updaten). */
         std::map<int, size_t> class_channels;                    /* fast-IIR class (per stage) -> channels */
-        auto class_of = [](const Design &d, int stage) { return 64 * stage + 2 * (d.nb - 1) + (d.a[0] == 1.0 ? 1 : 0); };
+        auto class_of = [](const Design &d, int stage) {
+            return d.sos_fused ? 100000 + d.fast_n() : 64 * stage + 2 * (d.nb - 1) + (d.a[0] == 1.0 ? 1 : 0);
+        };
         std::vector<int> design_stage(bk->designs.size(), 0);
         for (size_t c = 0; c < bk->nch; ++c)
             for (int k = 0; k < stages_of(c); ++k) {
                 const int di = stage_design(c, k);
                 const Design &d = bk->designs[di];
                 design_stage[di] = k;
-                if (d.fast_iir()) class_channels[class_of(d, k)]++;
+                if (d.fast()) class_channels[class_of(d, k)]++;
             }
         const bool with_ttab = bk->designs.size() <= kMaxPipeDesigns;
         size_t ncoef = 0, npow = 0;
         for (size_t di = 0; di < bk->designs.size(); ++di) {
             Design &d = bk->designs[di];
             d.has_tables = false;
-            if (d.fast_iir()) {
-                const int N = d.nb - 1;
+            if (d.fast()) {
+                const int N = d.fast_n();
                 const auto it = class_channels.find(class_of(d, design_stage[di]));
                 const size_t width = it == class_channels.end() ? 0 : it->second;
                 d.has_tables = width > 0 && !(N <= kScan2MaxOrder && width >= kSeqOnlyChannels);
@@ -981,7 +1147,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
                 Design &d = bk->designs[i];
                 if (!d.has_tables) continue;
                 const size_t base = (size_t)d.pow_off;
-                const DesignTables t = build_design_tables(d, with_ttab, probe_kernel_of(d.nb - 1, nd), mine);
+                const DesignTables t = build_design_tables(d, with_ttab, probe_kernel_of(d.fast_n(), nd), mine);
                 d.scan_error = t.scan_error;
                 d.levels1 = t.levels1;
                 d.levels2 = t.levels2;
@@ -1024,7 +1190,10 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             const int di = stage_design(c, stage);
             const Design &d = bk->designs[di];
             int cls, sub = 0;
-            if (d.kind != RTFB_KIND_IIR) cls = kFir;
+            if (d.sos_fused) {
+                cls = kIirFast;
+                sub = 1024 + 4 * d.fast_n() + 2 + (d.scan_safe() ? 1 : 0);       /* a0 == 1 in every section */
+            } else if (d.kind != RTFB_KIND_IIR) cls = kFir;
             else if (d.fast_iir()) {
                 cls = kIirFast;
                 sub = 4 * (d.nb - 1) + (d.a[0] == 1.0 ? 2 : 0) + (d.scan_safe() ? 1 : 0);
@@ -1035,7 +1204,8 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
                 Group g;
                 g.cls = (GroupClass)cls;
                 g.stage = stage;
-                g.order = sub / 4;
+                g.order = (sub & 1023) / 4;
+                g.sos_sections = sub >= 1024 ? g.order / 2 : 0;
                 g.unit_a0 = (sub & 2) != 0;
                 g.scan_safe = (sub & 1) != 0;
                 it = index.emplace(key, bk->groups.size()).first;
@@ -1046,8 +1216,8 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             g.chan_design.push_back(di);
             g.state_ld = std::max(g.state_ld, d.state_slots());
             g.levels2_max = std::max(g.levels2_max, d.levels2);
-            if (d.fast_iir() && !d.has_tables) g.has_tables = false;
-            if (d.kind != RTFB_KIND_IIR) g.kmax = std::max(g.kmax, d.nb);
+            if (d.fast() && !d.has_tables) g.has_tables = false;
+            if (d.kind != RTFB_KIND_IIR && !d.sos_fused) g.kmax = std::max(g.kmax, d.nb);
             if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
             if (g.single_design == -2) g.single_design = di;
             else if (g.single_design != di) g.single_design = -1;
@@ -1084,7 +1254,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             ini[i] = init_init.empty() ? FILTER_RESET : init_init[c];
             if (!init_state.empty()) {
                 /* a section of an SOS channel owns slots [3 stage, 3 stage + 3) of the channel's state row */
-                const bool sos = bk->designs[bk->design_of[c]].kind == RTFB_KIND_SOS;
+                const bool sos = staged(bk->designs[bk->design_of[c]]);
                 const int slots = bk->designs[dsn[i]].state_slots();
                 const size_t off = sos ? (size_t)3 * g.stage : 0;
                 for (int k = 0; k < slots; ++k) st[i * g.state_ld + k] = init_state[c * ld + off + k];
@@ -1171,7 +1341,8 @@ Group *chain_group(RTFilterBank *bk)
 {
     if (bk->groups.size() != 1) return nullptr;
     Group &g = bk->groups[0];
-    if (g.cls != kIirFast || g.stage != 0 || g.order < 1 || g.order > kScan2MaxOrder || !g.has_tables) return nullptr;
+    if (g.cls != kIirFast || g.stage != 0 || g.order < 1 || g.order > kScan2MaxOrder || !g.has_tables || g.sos_sections)
+        return nullptr;
     if (bk->designs.size() > kMaxPipeDesigns) return nullptr;
     if (bk->mode == RTFB_MODE_SEQUENTIAL || (bk->mode == RTFB_MODE_AUTO && !g.scan_safe)) return nullptr;
     return &g;
@@ -1733,6 +1904,13 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
         bool seq = bank->mode == RTFB_MODE_SEQUENTIAL || !g.has_tables ||
                    (bank->mode == RTFB_MODE_AUTO && (!g.scan_safe || g.chans.size() >= seq_from));
         if (!seq && !iir_scan_supported(g.order)) seq = true;
+        if (g.sos_sections) {
+            /* fused cascades: all sections per sample, one pass (bit-exact lane-per-channel kernel or the
+             * pipelined kernel on the cascade's 2-states-per-section system) */
+            if (seq) HIP_TRY(launch_iir_seq_sos(g.sos_sections, v, io, s));
+            else HIP_TRY(launch_iir_pipe_sos(g.sos_sections, v, io, s));
+            continue;
+        }
         if (seq) HIP_TRY(launch_iir_seq(g.order, v, io, s));
         else if (g.order <= kScan2MaxOrder && bank->designs.size() <= kMaxPipeDesigns)
             HIP_TRY(launch_iir_pipe(g.order, v, io, s));            /* per-design row propagators resident */
@@ -2036,7 +2214,7 @@ int RTFilterBank_get_state(RTFilterBank *bank, double *state, double *fval, int3
         for (size_t i = 0; i < cnt; ++i) {
             const size_t c = (size_t)g.chans[i];
             const Design &cd = bank->designs[bank->design_of[c]];
-            if (cd.kind == RTFB_KIND_SOS) {
+            if (cd.kind == RTFB_KIND_SOS && !cd.sos_fused) {
                 /* section `stage` owns slots [3 stage, 3 stage + 3); the last section's output is the channel's
                  * filtered_value; every section carries the same `initialized` */
                 const size_t off = (size_t)3 * g.stage;
@@ -2079,7 +2257,8 @@ int RTFilterBank_set_state(RTFilterBank *bank, const double *state, const double
             std::vector<double> st(cnt * (size_t)g.state_ld);
             for (size_t i = 0; i < cnt; ++i) {
                 const size_t c = (size_t)g.chans[i];
-                const size_t off = bank->designs[bank->design_of[c]].kind == RTFB_KIND_SOS ? (size_t)3 * g.stage : 0;
+                const Design &cd = bank->designs[bank->design_of[c]];
+                const size_t off = (cd.kind == RTFB_KIND_SOS && !cd.sos_fused) ? (size_t)3 * g.stage : 0;
                 for (int k = 0; k < g.state_ld; ++k)
                     st[i * g.state_ld + k] = off + k < ld ? state[c * ld + off + k] : 0.0;
             }
@@ -2116,7 +2295,7 @@ int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream)
                           ? reinterpret_cast<RTFIRFilter *>(f)->state
                           : reinterpret_cast<RTIIRFilter *>(f)->state;
         if (d.kind == RTFB_KIND_SOS) {              /* the host filter keeps two doubles per section */
-            for (size_t k = 0; k < d.section_design.size(); ++k) {
+            for (size_t k = 0; k < (size_t)d.nb / 3; ++k) {
                 dst[2 * k] = st[c * ld + 3 * k];
                 dst[2 * k + 1] = st[c * ld + 3 * k + 1];
             }

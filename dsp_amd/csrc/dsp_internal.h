@@ -129,6 +129,10 @@ hipError_t launch_chain_unpack(const double *records, double *state, double *fva
 hipError_t launch_tile_rows(double *dst, const double *src, size_t ld, size_t nch, size_t n, int to_tiles,
                             hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
+/* fused second-order sections (1 .. kMaxFusedSections per channel, a0 == 1): all sections per sample in one pass */
+constexpr int kMaxFusedSections = 4;
+hipError_t launch_iir_seq_sos(int sections, const GroupView &g, const BlockIO &io, hipStream_t s);
+hipError_t launch_iir_pipe_sos(int sections, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 /* false when launch_fir takes the lane-per-channel kernel, which updates g.state in place (no ping-pong swap) */
 bool fir_uses_state_swap(const GroupView &g, const BlockIO &io);

@@ -73,6 +73,82 @@ __device__ __forceinline__ double iir_seed_ref(double x, double (&s)[N + 1],
     return d * x;
 }
 
+/* ---- second-order sections (RTFB_KIND_SOS, include/RTFilterDesign.h) ------------------------------------------
+ * S sections; section k is an RTIIRFilter with nb = na = 3 (taps sb[3k..3k+2], sa[3k..3k+2]) run on the output of
+ * section k-1 -- per SAMPLE here, so that a block is read and written once for the whole cascade (round 2 ran
+ * one pass over memory per section). */
+
+/* reference operation order per section (iir_step_ref<2>), state 3 slots per section, s[3k+2] read, never written */
+template <int S, bool kUnitA0>
+__device__ __forceinline__ double sos_step_ref(double x, double (&s)[3 * S], const double (&sb)[3 * S],
+                                               const double (&sa)[3 * S])
+{
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        double t = x * sb[3 * k];
+        t = t + s[3 * k];
+        double y = t;
+        if (!kUnitA0) y = t / sa[3 * k];
+        double u = 0.0 + sb[3 * k + 1] * x;
+        u = u - sa[3 * k + 1] * y;
+        s[3 * k] = s[3 * k + 1] + u;
+        u = 0.0 + sb[3 * k + 2] * x;
+        u = u - sa[3 * k + 2] * y;
+        s[3 * k + 1] = s[3 * k + 2] + u;
+        x = y;
+    }
+    return x;
+}
+
+/* RTIIRFilter_stable_init of every section on the first sample of ITS input (the seeded output of the one before) */
+template <int S>
+__device__ __forceinline__ double sos_seed_ref(double x, double (&s)[3 * S], const double (&sb)[3 * S],
+                                               const double (&sa)[3 * S])
+{
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        double s3[3], b3[3] = {sb[3 * k], sb[3 * k + 1], sb[3 * k + 2]}, a3[3] = {sa[3 * k], sa[3 * k + 1], sa[3 * k + 2]};
+        x = iir_seed_ref<2>(x, s3, b3, a3);
+        s[3 * k] = s3[0];
+        s[3 * k + 1] = s3[1];
+        s[3 * k + 2] = s3[2];
+    }
+    return x;
+}
+
+/* The cascade as ONE state-space system of 2 S states z = (s^1_0, s^1_1, s^2_0, ...) for the time-parallel kernel
+ * (fused multiply-adds; the third slot of a section is 0 in every state the library produces and is not an input
+ * here); z has room for the kernel's tail slot z[2S], unused. */
+template <int S, bool kUnitA0>
+__device__ __forceinline__ double sos_step_fused(double x, double (&z)[2 * S + 1], const double (&sb)[3 * S],
+                                                 const double (&sa)[3 * S])
+{
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        double y = __builtin_fma(x, sb[3 * k], z[2 * k]);
+        if (!kUnitA0) y = y / sa[3 * k];
+        z[2 * k] = __builtin_fma(-sa[3 * k + 1], y, __builtin_fma(sb[3 * k + 1], x, z[2 * k + 1]));
+        z[2 * k + 1] = __builtin_fma(-sa[3 * k + 2], y, sb[3 * k + 2] * x);
+        x = y;
+    }
+    return x;
+}
+
+template <int S>
+__device__ __forceinline__ double sos_seed_z(double x, double (&z)[2 * S + 1], const double (&sb)[3 * S],
+                                             const double (&sa)[3 * S])
+{
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        double s3[3], b3[3] = {sb[3 * k], sb[3 * k + 1], sb[3 * k + 2]}, a3[3] = {sa[3 * k], sa[3 * k + 1], sa[3 * k + 2]};
+        x = iir_seed_ref<2>(x, s3, b3, a3);
+        z[2 * k] = s3[0];
+        z[2 * k + 1] = s3[1];
+    }
+    z[2 * S] = 0.0;
+    return x;
+}
+
 }  // namespace dsp
 
 #endif

@@ -50,11 +50,15 @@ __device__ __forceinline__ double shfl_f64(double v, int src)
 /* A wavefront owns 64 channels and walks time in tiles of T samples; state   */
 /* and coefficients stay in registers for the whole block.                    */
 
-template <int N, int T, bool kUnitA0>
+/* kSos: the channels are cascades of N / 2 second-order sections (RTFB_KIND_SOS), all sections of a sample in
+ * registers: coefficients and state are 3 per section instead of N + 1. */
+template <int N, int T, bool kUnitA0, bool kSos = false>
 __global__ void __launch_bounds__(kWave)
 iir_seq_kernel(GroupView g, BlockIO io)
 {
     using TG = Tile<T>;
+    static_assert(!kSos || N % 2 == 0, "two states per section");
+    constexpr int kNC = kSos ? 3 * (N / 2) : N + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x;
@@ -64,20 +68,28 @@ iir_seq_kernel(GroupView g, BlockIO io)
     const int gc = live ? gi : g.count - 1;
     const int chan = group_channel(g, gc);
 
-    double b[N + 1], a[N + 1], s[N + 1];
+    double b[kNC], a[kNC], s[kNC];
     {
         const double *cf = g.coefs + g.coef_off[g.design[gc]];
 #pragma unroll
-        for (int i = 0; i <= N; ++i) {
+        for (int i = 0; i < kNC; ++i) {
             b[i] = cf[i];
-            a[i] = cf[N + 1 + i];
+            a[i] = cf[kNC + i];
         }
         const double *st = g.state + (size_t)gc * g.state_ld;
 #pragma unroll
-        for (int i = 0; i <= N; ++i) s[i] = st[i];
+        for (int i = 0; i < kNC; ++i) s[i] = st[i];
     }
     double y = g.fval[gc];
     int ini = g.init[gc];
+    auto seed = [&](double x) {
+        if constexpr (kSos) return sos_seed_ref<N / 2>(x, s, b, a);
+        else return iir_seed_ref<N>(x, s, b, a);
+    };
+    auto step = [&](double x) {
+        if constexpr (kSos) return sos_step_ref<N / 2, kUnitA0>(x, s, b, a);
+        else return iir_step_ref<N, kUnitA0>(x, s, b, a);
+    };
 
     const size_t n = io.n;
 
@@ -112,10 +124,10 @@ iir_seq_kernel(GroupView g, BlockIO io)
 #pragma unroll 2
             for (int k = 0; k < T; k += 2) {
                 d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
-                if (ini != 0) { y = iir_seed_ref<N>(xv.x, s, b, a); ini = 0; }
-                else y = iir_step_ref<N, kUnitA0>(xv.x, s, b, a);
+                if (ini != 0) { y = seed(xv.x); ini = 0; }
+                else y = step(xv.x);
                 xv.x = y;
-                y = iir_step_ref<N, kUnitA0>(xv.y, s, b, a);
+                y = step(xv.y);
                 xv.y = y;
                 *reinterpret_cast<d2 *>(row + k * 8) = xv;
             }
@@ -157,11 +169,11 @@ iir_seq_kernel(GroupView g, BlockIO io)
         char *row = smem + lane * TG::kRowBytes;
         for (int k = 0; k < cnt; k += 2) {
             d2 xv = *reinterpret_cast<d2 *>(row + k * 8);
-            if (ini != 0) { y = iir_seed_ref<N>(xv.x, s, b, a); ini = 0; }
-            else y = iir_step_ref<N, kUnitA0>(xv.x, s, b, a);
+            if (ini != 0) { y = seed(xv.x); ini = 0; }
+            else y = step(xv.x);
             xv.x = y;
             if (k + 1 < cnt) {
-                y = iir_step_ref<N, kUnitA0>(xv.y, s, b, a);
+                y = step(xv.y);
                 xv.y = y;
             }
             *reinterpret_cast<d2 *>(row + k * 8) = xv;
@@ -194,7 +206,7 @@ iir_seq_kernel(GroupView g, BlockIO io)
     if (live) {
         double *st = g.state + (size_t)gi * g.state_ld;
 #pragma unroll
-        for (int i = 0; i <= N; ++i) st[i] = s[i];
+        for (int i = 0; i < kNC; ++i) st[i] = s[i];
         g.fval[gi] = y;
         g.init[gi] = ini;
     }
@@ -1003,6 +1015,22 @@ static hipError_t launch_scan_n(const GroupView &g, const BlockIO &io, hipStream
 
 #define DSP_FOR_EACH_ORDER(X) \
     X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+/* cascades of `sections` second-order sections, every a0 == 1 (bank.hip fuses only those) */
+hipError_t launch_iir_seq_sos(int sections, const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    const int blocks = (g.count + kWave - 1) / kWave;
+    switch (sections) {
+#define X(S)                                                                                                   \
+    case S:                                                                                                    \
+        hipLaunchKernelGGL((iir_seq_kernel<2 * S, kSeqT, true, true>), dim3(blocks), dim3(kWave), Tile<kSeqT>::kBytes, \
+                           s, g, io);                                                                          \
+        return hipGetLastError();
+        X(1) X(2) X(3) X(4)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s)
 {

@@ -103,12 +103,18 @@ __device__ __forceinline__ d2 record_load(const double *rec, int cnt, unsigned i
     }
 }
 
-/* kChain (whole-segment launches only): the launch is one link of a chain, see ChainView. */
-template <int N, bool kUnitA0, bool kWhole, bool kChain>
+/* kChain (whole-segment launches only): the launch is one link of a chain, see ChainView.
+ * kSos: every channel is a cascade of N / 2 second-order sections run as ONE state-space system of N states
+ * (iir_steps.h: sos_step_fused): the tables G, A^(32 2^k), A^(32 j) are those of the cascade's block-triangular
+ * system matrix (bank.hip), the true pass runs the sections one after the other per sample; coefficients and the
+ * state row are 3 per section. */
+template <int N, bool kUnitA0, bool kWhole, bool kChain, bool kSos = false>
 __global__ void __launch_bounds__(2 * kWave, 2)
 iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
 {
     static_assert(kWhole || !kChain, "chained launches consist of whole segments");
+    static_assert(!kSos || (N % 2 == 0 && !kChain), "two states per section; cascades are not chained");
+    constexpr int kNC = kSos ? 3 * (N / 2) : N + 1;         /* taps per coefficient array */
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *tile0 = smem;
     char *tile1 = smem + kPTile;
@@ -185,7 +191,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
     /* wave-uniform words of this launch's inputs come through scalar loads: a vector load issued next to the
      * segment prefetch below would make its first use wait for the whole prefetch (vmcnt counts in order) */
     bool seed_stream = as_const(g.init)[gi] != 0;
-    double tail0 = as_const(g.state)[(size_t)gi * g.state_ld + N];     /* s[N]: read, never written */
+    double tail0 = kSos ? 0.0 : as_const(g.state)[(size_t)gi * g.state_ld + N];     /* s[N]: read, never written */
     double *rec = nullptr;
     if constexpr (kChain) {
         rec = ext.chain.records + (size_t)gi * (2 * (N + 2));
@@ -321,13 +327,21 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
 
     /* coefficients live in SGPRs; the front wave only needs them for the seeded first row and loads them
      * there, so that its scalar registers stay free for the table batches */
-    auto load_coefs = [&](double(&b)[N + 1], double(&a)[N + 1]) {
+    auto load_coefs = [&](double(&b)[kNC], double(&a)[kNC]) {
         cdouble_p cf = as_const(g.coefs) + as_const(g.coef_off)[dsn];
 #pragma unroll
-        for (int i = 0; i <= N; ++i) {
+        for (int i = 0; i < kNC; ++i) {
             b[i] = cf[i];
-            a[i] = cf[N + 1 + i];
+            a[i] = cf[kNC + i];
         }
+    };
+    auto seed = [](double x, double(&s)[N + 1], const double(&b)[kNC], const double(&a)[kNC]) {
+        if constexpr (kSos) return sos_seed_z<N / 2>(x, s, b, a);
+        else return iir_seed_ref<N>(x, s, b, a);
+    };
+    auto step = [](double x, double(&s)[N + 1], const double(&b)[kNC], const double(&a)[kNC]) {
+        if constexpr (kSos) return sos_step_fused<N / 2, kUnitA0>(x, s, b, a);
+        else return iir_step_fused<N, kUnitA0>(x, s, b, a);
     };
 
     if (front) {
@@ -435,15 +449,14 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             if (seeded && lane == 0) {
                 /* row 0 of a fresh stream: RTIIRFilter_stable_init on sample 0, then the recurrence;
                  * its end state does not depend on any carried state */
-                double b[N + 1], a[N + 1];
+                double b[kNC], a[kNC];
                 load_coefs(b, a);
 #pragma unroll
                 for (int i = 0; i <= N; ++i) v[i] = 0.0;
                 const size_t left = n < (size_t)PT ? n : (size_t)PT;
-                (void)iir_seed_ref<N>(*reinterpret_cast<const double *>(row + (0 ^ rx)), v, b, a);
+                (void)seed(*reinterpret_cast<const double *>(row + (0 ^ rx)), v, b, a);
                 for (int k = 1; k < (int)left; ++k)
-                    (void)iir_step_fused<N, kUnitA0>(
-                        *reinterpret_cast<const double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8), v, b, a);
+                    (void)step(*reinterpret_cast<const double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8), v, b, a);
             }
 
             /* Kogge-Stone over the 64 rows, zero carry-in.  The level's matrix A^(32 d) is wave-uniform: it
@@ -528,7 +541,7 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
 
     } else {
         /* =============================== BACK ================================ */
-        double b[N + 1], a[N + 1];
+        double b[kNC], a[kNC];
         load_coefs(b, a);
         double carry[N + 1];
         double ylast;
@@ -538,6 +551,15 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             for (int i = 0; i <= N; ++i) carry[i] = __shfl(gv.x, i, kWave);
             ylast = __shfl(gv.x, N + 1, kWave);
             if (lane == 0) xch[0] = carry[N];             /* for the front wave, read behind the first barriers */
+        } else if constexpr (kSos) {
+            const double *st = g.state + (size_t)gi * g.state_ld;       /* 3 slots per section, the third is 0 */
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) {
+                carry[2 * k] = st[3 * k];
+                carry[2 * k + 1] = st[3 * k + 1];
+            }
+            carry[N] = 0.0;
+            ylast = g.fval[gi];
         } else {
             const double *st = g.state + (size_t)gi * g.state_ld;
 #pragma unroll
@@ -626,8 +648,8 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
 #pragma unroll
                     for (int q = 0; q < kBurst; ++q) {
                         d2 xv = xr[q];
-                        xv.x = iir_step_fused<N, kUnitA0>(xv.x, s, b, a);
-                        xv.y = y = iir_step_fused<N, kUnitA0>(xv.y, s, b, a);
+                        xv.x = step(xv.x, s, b, a);
+                        xv.y = y = step(xv.y, s, b, a);
                         *reinterpret_cast<d2 *>(row + (((h + q) << 4) ^ rx)) = xv;
                     }
                 }
@@ -637,13 +659,13 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
                 int k = 0;
                 if (seeded && lane == 0) {
                     double *p0 = reinterpret_cast<double *>(row + (0 ^ rx));
-                    y = iir_seed_ref<N>(*p0, s, b, a);
+                    y = seed(*p0, s, b, a);
                     *p0 = y;
                     k = 1;
                 }
                 for (; k < cnt; ++k) {
                     double *pk = reinterpret_cast<double *>(row + (((k >> 1) << 4) ^ rx) + (k & 1) * 8);
-                    y = iir_step_fused<N, kUnitA0>(*pk, s, b, a);
+                    y = step(*pk, s, b, a);
                     *pk = y;
                 }
             }
@@ -691,8 +713,17 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             }
         } else if (lane == 0) {
             double *st = g.state + (size_t)gi * g.state_ld;
+            if constexpr (kSos) {
 #pragma unroll
-            for (int i = 0; i <= N; ++i) st[i] = carry[i];
+                for (int k = 0; k < N / 2; ++k) {
+                    st[3 * k] = carry[2 * k];
+                    st[3 * k + 1] = carry[2 * k + 1];
+                    st[3 * k + 2] = 0.0;                   /* what stable_init leaves there; never written afterwards */
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i <= N; ++i) st[i] = carry[i];
+            }
             g.fval[gi] = ylast;
             g.init[gi] = 0;
             if (dbg) dbg[5] = __builtin_amdgcn_s_memrealtime();                            /* back done */
@@ -856,6 +887,48 @@ hipError_t launch_tile_rows(double *dst, const double *src, size_t ld, size_t nc
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)nch, (unsigned)(n / kPSeg)), dim3(256), 0, s, dst, src, ld,
                        nch, n / kPSeg, to_tiles);
     return hipGetLastError();
+}
+
+template <int S>
+static hipError_t launch_pipe_sos_n(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    constexpr int N = 2 * S;
+    const size_t lds = 2 * kPTile + sizeof(double) * (size_t)kPRows * (N + 2);
+    const bool whole = io.aligned16 && io.n % kPSeg == 0;
+    const int round = pipe_resident_round();
+    PipeExt ext = {};
+    ext.seg_in = ext.seg_out = kPSeg;
+    /* a little wider than one resident round: round by round, as launch_pipe_n */
+    const int stepc = (g.count > round && g.count <= 4 * round) ? round : g.count;
+    for (int off = 0; off < g.count; off += stepc) {
+        GroupView h = g;
+        h.chan = g.chan ? g.chan + off : nullptr;
+        h.chan0 = g.chan0 + off;
+        h.count = g.count - off < stepc ? g.count - off : stepc;
+        h.design = g.design + off;
+        h.state = g.state + (size_t)off * g.state_ld;
+        h.fval = g.fval + off;
+        h.init = g.init + off;
+        if (whole)
+            hipLaunchKernelGGL((iir_pipe_kernel<N, true, true, false, true>), dim3(h.count), dim3(2 * kWave), lds, s, h, io, ext);
+        else
+            hipLaunchKernelGGL((iir_pipe_kernel<N, true, false, false, true>), dim3(h.count), dim3(2 * kWave), lds, s, h, io, ext);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_iir_pipe_sos(int sections, const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    static_assert(kMaxFusedSections == 4, "one instantiation per section count");
+    switch (sections) {
+        case 1: return launch_pipe_sos_n<1>(g, io, s);
+        case 2: return launch_pipe_sos_n<2>(g, io, s);
+        case 3: return launch_pipe_sos_n<3>(g, io, s);
+        case 4: return launch_pipe_sos_n<4>(g, io, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_iir_pipe(int order, const GroupView &g, const BlockIO &io, hipStream_t s)

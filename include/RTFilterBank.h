@@ -47,7 +47,13 @@ typedef struct RTFilterBank RTFilterBank;
                                       their denominators.  Every section is executed as an RTIIRFilter with
                                       nb = na = 3 (RTIIRFilter_update + RTIIRFilter_stable_init) on the output of
                                       the section before it; state: 3 slots per section, filtered_value of the
-                                      last section.  One pass over the block per section (16 B/sample each). */
+                                      last section.  Cascades of up to 4 sections with a0 == 1 in every section
+                                      are FUSED: all sections per sample, the block read and written once (the
+                                      cascade as one state-space system of 2 states per section on the pipelined
+                                      kernel, or the bit-exact lane-per-channel kernel); longer cascades run one
+                                      pass over the block per section.  The third state slot of a section (read,
+                                      never written; 0 in every state the library produces) is honoured by the
+                                      bit-exact kernels only. */
 
 /* One distinct coefficient set; channels reference designs by index. */
 typedef struct RTFilterDesign {
