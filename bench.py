@@ -102,7 +102,45 @@ def cpu_baseline(b, a):
                        % (threads * per_thread, DESIGN, threads, dt))
 
 
-def measured_traffic(name="r2_traffic.json"):
+def device_state_under_load(run_step, sync):
+    """Clocks and power as rocm-smi reports them WHILE the hot path runs (untimed; the pool's boxes differ by a
+    few per cent from process to process: the copy ceiling measured in the same run is the yardstick, these
+    readings are the context for it).  None where rocm-smi is missing or refuses."""
+    import re
+    import subprocess
+    import threading
+    out = {}
+
+    def probe():
+        try:
+            r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True,
+                               timeout=20)
+            out["text"] = r.stdout
+        except Exception as exc:                         # noqa: BLE001  (diagnostic only)
+            out["error"] = repr(exc)
+
+    th = threading.Thread(target=probe)
+    th.start()
+    t0 = time.perf_counter()
+    while th.is_alive() and time.perf_counter() - t0 < 20.0:
+        for _ in range(64):
+            run_step()
+        sync()
+    th.join()
+    txt = out.get("text")
+    if not txt:
+        return None
+    state = {}
+    for key, pat in (("mclk_mhz", r"mclk clock level: \d+: \((\d+)Mhz\)"), ("sclk_mhz", r"sclk clock level: \d+: \((\d+)Mhz\)"),
+                     ("fclk_mhz", r"fclk clock level: \d+: \((\d+)Mhz\)"),
+                     ("power_w", r"Power \(W\): ([0-9.]+)")):
+        m = re.search(pat, txt)
+        if m:
+            state[key] = float(m.group(1))
+    return state or None
+
+
+def measured_traffic(name="r3_traffic.json"):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/:
     FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, KiB -> bytes).  A stored constant, not
     something this run measured (bench.py does not run the profiler): the bench line names the file under
@@ -153,6 +191,9 @@ def main():
                     help="untimed: keep the GPU busy with the hot path for this long BEFORE the warm-up steps, so "
                          "that the shader/memory clocks have left their idle state (a step takes ~4 %% longer "
                          "during the first ~25 ms after an idle period: tools/rampup.py); 0 disables")
+    ap.add_argument("--no-others", action="store_true",
+                    help="config 2: skip the untimed legs that time the other hand-overs (rows / chained) and the cold "
+                         "pass -- profiling runs, so that every launch of the dominant kernel has the timed shape")
     ap.add_argument("--no-extra", action="store_true",
                     help="default run only: skip the compact config-3 and config-5 legs attached under `other_configs`")
     args = ap.parse_args()
@@ -242,7 +283,7 @@ def main():
 
     # untimed extra, first thing after an idle pause: the same K steps from cold clocks (no settle pass, no warm-up)
     cold_value = None
-    if args.settle_ms > 0:
+    if args.settle_ms > 0 and not args.no_others:
         time.sleep(0.25)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(stream)
@@ -263,6 +304,9 @@ def main():
             step()
         settle_steps += 32
         torch.cuda.synchronize()
+    dev_state = None
+    if rank == 0 and args.settle_ms > 0 and not args.no_others:
+        dev_state = device_state_under_load(step, torch.cuda.synchronize)
     if settle_steps:
         step_no[0] = 0
         bank.reset(stream)
@@ -327,7 +371,7 @@ def main():
 
     # untimed extra, rank 0: the other ways the same blocks can be handed over (same bank design, fresh banks)
     others = {}
-    if rank == 0 and not args.jitter:
+    if rank == 0 and not args.jitter and not args.no_others:
         def leg(layout_tiled, chained):
             bk = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
             if layout_tiled == tiled:
@@ -385,7 +429,7 @@ def main():
                        "kernel": args.mode, "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "traffic_source": "profiles/r2_traffic.json (rocprofv3 --pmc passes of this command, committed; "
+                         "traffic_source": "profiles/r3_traffic.json (rocprofv3 --pmc passes of this command, committed; "
                                            "not re-measured by this run)",
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE,
                          "copy_ceiling_measured": copy_gbs,
@@ -393,6 +437,7 @@ def main():
                          "kernel_ms_avg": kern_avg_s * 1e3,
                          "single_launch_ms_avg": float(np.mean(kern_ms)), "single_launch_ms_min": float(np.min(kern_ms))},
             "cold_start_msamples_s": cold_value,
+            "device_state_under_load": dev_state,
             "other_hand_overs_msamples_s": others,
         }
         if world == 1 and not args.no_cpu:
@@ -504,7 +549,7 @@ def main_fir512(args, emit=True):
                        "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TF,
-                         "traffic": measured_traffic("r2_fir512_traffic.json") if nch == 65536 else None,
+                         "traffic": measured_traffic("r3_fir512_traffic.json") if nch == 65536 else None,
                          "algorithmic_flops_per_launch": flops,
                          "hbm_gbs_at_16B_per_sample": samples * BYTES_PER_SAMPLE / kern_avg_s / 1e9,
                          "kernel_ms_avg": kern_avg_s * 1e3, "kernel_ms_min": float(np.min(kern_ms))},
@@ -795,14 +840,14 @@ def main_stream16(args, emit=True):
                        "parallelism": "time-split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (2 * measured_traffic("r2_config5_traffic.json")
+                         "traffic": (2 * measured_traffic("r3_config5_traffic.json")
                                      if world == 1 and args.stream_log2 == 30
-                                     and measured_traffic("r2_config5_traffic.json") else None),
+                                     and measured_traffic("r3_config5_traffic.json") else None),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
                          "note": "per-GPU bytes of one step (the run-up launch over the sub-chunks' tails, the main "
                                  "launch of the scan kernel over all sub-chunks, state copies) over the step's device "
                                  "time on rank 0; traffic = PMC bytes of the two launches "
-                                 "(profiles/r2_config5_traffic.json, committed; not re-measured by this run)",
+                                 "(profiles/r3_config5_traffic.json, committed; not re-measured by this run)",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         if world == 1 and not args.no_cpu:

@@ -148,6 +148,8 @@ class FilterBank:
 
     def close(self):
         if self._handle:
+            for feed in list(getattr(self, "_feeds", ())):      # a feed refers to the C handle: close it first
+                feed.close()
             dspdll.RTFilterBank_destroy(self._handle)
             self._handle = C.c_void_p()
 
@@ -302,11 +304,15 @@ class BankFeed:
         self.bank = bank
         self.nch = bank.nch
         _check(dspdll.RTFilterBankFeed_create(C.byref(self._h), bank._handle, block_frames), "RTFilterBankFeed_create")
+        bank.__dict__.setdefault("_feeds", []).append(self)       # FilterBank.close() closes its live feeds first
 
     def close(self):
         if self._h:
             dspdll.RTFilterBankFeed_destroy(self._h)
             self._h = C.c_void_p()
+            feeds = self.bank.__dict__.get("_feeds", [])
+            if self in feeds:
+                feeds.remove(self)
 
     def __del__(self):
         try:

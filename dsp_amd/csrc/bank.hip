@@ -2794,6 +2794,7 @@ int RTFilterStream_set_state(RTFilterStream *st, const double *state, const doub
 
 struct RTFilterBankFeed {
     RTFilterBank *bank = nullptr;
+    int device = 0;                          /* the bank's device, kept here: the feed may outlive the bank's handle */
     size_t nch = 0, block = 0;               /* frames per device block */
     hipStream_t s = nullptr;
     double *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};      /* pinned, time-major [block][nch] */
@@ -2810,7 +2811,7 @@ namespace {
 
 void feed_release(RTFilterBankFeed *f)
 {
-    DeviceScope ds(f->bank->device);
+    DeviceScope ds(f->device);               /* not f->bank->device: the bank may already be destroyed */
     if (f->s) (void)hipStreamSynchronize(f->s);
     for (int k = 0; k < 2; ++k) {
         if (f->h_in[k]) (void)hipHostFree(f->h_in[k]);
@@ -2856,6 +2857,7 @@ int RTFilterBankFeed_create(RTFilterBankFeed **feed, RTFilterBank *bank, size_t 
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
     RTFilterBankFeed *f = new RTFilterBankFeed;
     f->bank = bank;
+    f->device = bank->device;
     f->nch = bank->nch;
     f->block = block_frames;
     const size_t bytes = f->nch * f->block * sizeof(double);

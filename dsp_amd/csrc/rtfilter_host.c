@@ -368,6 +368,17 @@ int RTIIRFilter_stable_init(RTFilter *rtf, double sample)
 
 void RTIIRFilter_print(RTIIRFilter *rtif)
 {
+    if (rtif->rtf.update == RTIIRFilter_sos_update) {
+        /* FILTER_SOS: the bank holds packed sections (design_host.c: pack_sos), nb = their number */
+        RTFilterSection sec[DSP_MAX_SECTIONS];
+        size_t ns = 0;
+        if (RTIIRFilter_sos_sections(rtif, sec, DSP_MAX_SECTIONS, &ns)) return;
+        printf("IIR as %zu second-order sections:\n", ns);
+        for (size_t k = 0; k < ns; k++)
+            printf("  b = [%.17g, %.17g, %.17g]  a = [%.17g, %.17g, %.17g]\n", sec[k].b[0], sec[k].b[1], sec[k].b[2],
+                   sec[k].a[0], sec[k].a[1], sec[k].a[2]);
+        return;
+    }
     printf("IIR order %zu:\n", max_sz(rtif->ifb.na, rtif->ifb.fb.nb));
     IIRFilterBank_print(&rtif->ifb);
 }

@@ -89,9 +89,13 @@ class RTIIRFilter(_RTFilterObject):
         dspdll.RTIIRFilter_print(byref_(self._rtif))
 
     def b(self):
+        if self.is_sos():
+            raise ValueError("a FILTER_SOS filter holds packed sections, not b | a: use sections()")
         return tuple(self._b[: self._rtif.ifb.fb.nb])
 
     def a(self):
+        if self.is_sos():
+            raise ValueError("a FILTER_SOS filter holds packed sections, not b | a: use sections()")
         nb = self._rtif.ifb.fb.nb
         return tuple(self._b[nb: nb + self._rtif.ifb.na])
 

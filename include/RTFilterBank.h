@@ -74,7 +74,11 @@ typedef struct RTFilterDesign {
  *             falls from 4.7 at 2 taps to 3.5 at 32); short blocks on wide banks (>= 16384 channels,
  *             <= 4096 samples, <= 32 taps) stay on the bit-exact lane-per-channel kernel in every mode.
  * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
- * SCAN        like AUTO but IIR channels always on the scan kernel (no probe, caller's choice). */
+ * SCAN        like AUTO but IIR channels always on the scan kernels: the conditioning probe is bypassed, and with
+ *             it every accuracy promise -- the re-associated arithmetic then sits at the design's own conditioning
+ *             floor, which can be far above 1e-12 (19 of 200 random Butterworth designs of orders 10..16 exceeded
+ *             it in this mode, none under AUTO: DESIGN.md section 5; the demo's narrow band-pass is 5e-8 off).
+ *             For callers who have validated their designs themselves. */
 #define RTFB_MODE_AUTO        0
 #define RTFB_MODE_SEQUENTIAL  1
 #define RTFB_MODE_SCAN        2
@@ -212,7 +216,10 @@ EXPORT int RTFilterBank_updaten_host(RTFilterBank *bank, double *out, size_t ld_
  * channel and frame; latency is one block.  Two blocks may be in flight: when a third would be needed
  * before the oldest was popped, _push stops there and reports the frames it took in *accepted (RTFB_OK; with
  * accepted == NULL that situation is RTFB_ESIZE).  _pop never blocks (returns what is ready), _wait blocks until the
- * oldest submitted block is back; _flush submits a partial block and waits for everything in flight.  One producer/consumer thread per feed. */
+ * oldest submitted block is back; _flush submits a partial block and waits for everything in flight.  One producer/consumer thread per feed.
+ * Destroy a feed before its bank.  RTFilterBank_updaten_host and the feed run the bank on streams of their own:
+ * updates that the caller has enqueued on other streams for the same bank must have completed before (the carried
+ * state is not ordered between streams). */
 typedef struct RTFilterBankFeed RTFilterBankFeed;
 EXPORT int    RTFilterBankFeed_create(RTFilterBankFeed **feed, RTFilterBank *bank, size_t block_frames);
 EXPORT void   RTFilterBankFeed_destroy(RTFilterBankFeed *feed);

@@ -89,3 +89,28 @@ def test_noalloc_out_of_place_and_limit(G):
     torch.cuda.synchronize()
     ref_bank.close()
     na_bank.close()
+
+
+def test_noalloc_refusal_leaves_every_channel_untouched(G):
+    """A refused call enqueues nothing: with the IIR channels FIRST in the bank (their group would run before the
+    FIR group whose staging does not fit), the buffer and the carried state of every channel are what they were."""
+    import torch
+    from dsp_amd import bank as gbank
+    designs = [G.golden_design("bw4_bp_0.3_0.6"), G.golden_design("fir32_lp_0.25")]
+    idx = [0, 0, 0, 1, 1, 0]                           # an IIR channel at index 0
+    bank = gbank.FilterBank(designs, idx, mode=gbank.MODE_AUTO)
+    nch = len(idx)
+    warm = G.to_dev(G.make_inputs(9, nch, 2048))
+    bank.updaten_ptr_noalloc(warm.data_ptr(), 2048, warm.data_ptr(), 2048, 2048)      # a state worth comparing
+    before = [np.array(a, copy=True) for a in bank.get_state()]
+    n_big = gbank.noalloc_max_doubles() // 2 + 8       # the two FIR rows alone exceed the static array
+    big = torch.rand((nch, n_big), dtype=torch.float64, device="cuda")
+    keep = big.clone()
+    with pytest.raises(gbank.DSPError) as ei:
+        bank.updaten_ptr_noalloc(big.data_ptr(), n_big, big.data_ptr(), n_big, n_big)
+    assert ei.value.status == gbank.cdsp.RTFB_ESIZE
+    torch.cuda.synchronize()
+    assert torch.equal(big, keep), "a refused call wrote into the caller's buffer"
+    for a, b in zip(before, bank.get_state()):
+        assert util.bits_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    bank.close()

@@ -38,7 +38,7 @@ def main():
     w = pick(s2["pmc_write"], "iir_pipe_kernel<8, true")[0]["WRITE_SIZE"]
     hbm = int(f * 1024 * 2 + w * 1024)
     alg = 1024 * 65536 * 16
-    json.dump({"kernel": "dsp::iir_pipe_kernel<8, true, true>",
+    json.dump({"kernel": "dsp::iir_pipe_kernel<8, true, true, false, false> (tiled layout, paced)",
                "source": "profiles/" + RND + "_config2_rocprofv3_summary.txt (tools/prof.sh: rocprofv3 --pmc FETCH_SIZE "
                          "GRBM_GUI_ACTIVE ; --pmc WRITE_SIZE ; bench.py --steps 32 --warmup 8 --no-cpu)",
                "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w, "correction": CORR,
