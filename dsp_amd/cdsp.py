@@ -225,6 +225,8 @@ _proto("RTFilterStream_export_state", c_int, [c_void_p, c_void_p, c_void_p])
 _proto("RTFilterStream_import_state", c_int, [c_void_p, c_void_p, c_void_p])
 _proto("RTFilterStream_tail_state", c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p])
 _proto("RTFilterStream_exact_split", c_int, [c_void_p])
+_proto("RTFilterStream_set_interleave", c_int, [c_void_p, c_int])
+_proto("RTFilterStream_interleaved", c_int, [c_void_p])
 _proto("RTFilterStream_zero_state", c_int, [c_void_p, c_void_p])
 _proto("RTFilterStream_compose_state", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
 _proto("RTFilterStream_get_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])

@@ -149,7 +149,33 @@ Pool &pool()
     return p;
 }
 
+/* DSP_AMD_POOL_POISON=1 (diagnostic): every block is handed out filled with 0xFF bytes (NaN as doubles, -1 as
+ * ints), so that a read of memory the library never wrote shows up in the results on every box, not only on one
+ * whose memory happens to hold something else than zeros. */
+static bool pool_poison()
+{
+    static const bool on = [] {
+        const char *e = getenv("DSP_AMD_POOL_POISON");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
+static int pool_alloc_raw(void **out, size_t bytes, int device);
+
 int pool_alloc(void **out, size_t bytes, int device)
+{
+    int rc = pool_alloc_raw(out, bytes, device);
+    if (!rc && pool_poison()) {
+        DeviceScope ds(device);
+        (void)hipDeviceSynchronize();
+        if (hipMemset(*out, 0xFF, Pool::bucket(bytes)) != hipSuccess) (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+    }
+    return rc;
+}
+
+static int pool_alloc_raw(void **out, size_t bytes, int device)
 {
     if (!out) return fail(RTFB_EINVAL, "dsp_pool_alloc: NULL result pointer");
     Pool &p = pool();
@@ -748,6 +774,21 @@ int scan2_levels(const double *pw, int N, int nlevels = kScan2Levels)
  * design rejects keeps the states at the input's scale while the output is
  * small; re-association error stays relative to the former). */
 constexpr double kScanSafeError = 1e-13;     /* 10x margin under the 1e-12 parity bar */
+
+/* orders 9..16: iir_scan16_kernel serves every shape.  The two-wave pipelined kernel (pipe16_kernel.hip) is an
+ * alternative for launches of whole 2048-sample segments, OFF by default: measured, it is no faster (DESIGN.md 4b:
+ * on this part the FP64 matrix instructions and the FP64 vector ALU draw on the same arithmetic rate, so splitting
+ * the stages over two waves overlaps nothing that the rate does not already bound).  DSP_AMD_PIPE16=1 turns it on
+ * for banks; RTFilterStream_set_interleave(stream, workgroups > 0) for a stream. */
+constexpr size_t kPipe16Seg = 2048;
+bool pipe16_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("DSP_AMD_PIPE16");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
 
 bool Design::scan_safe() const { return scan_error <= kScanSafeError; }
 
@@ -1915,7 +1956,9 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
         else if (g.order <= kScan2MaxOrder && bank->designs.size() <= kMaxPipeDesigns)
             HIP_TRY(launch_iir_pipe(g.order, v, io, s));            /* per-design row propagators resident */
         else if (g.order <= kScan2MaxOrder) HIP_TRY(launch_iir_scan2(g.order, v, io, s));   /* > 1024 designs */
-        else HIP_TRY(launch_iir_scan(g.order, v, io, s));           /* orders 9..16 */
+        else if (pipe16_enabled() && io.aligned16 && n % kPipe16Seg == 0)
+            HIP_TRY(launch_iir_pipe16(g.order, v, io, Pipe16Ext{}, 0, s));   /* orders 9..16, whole segments */
+        else HIP_TRY(launch_iir_scan(g.order, v, io, s));           /* orders 9..16, any shape */
     }
     return RTFB_OK;
 }
@@ -2344,6 +2387,12 @@ struct RTFilterStream {
     bool exact_ok = false;                    /* chunk maps may be composed exactly (scan-safe fast IIR) */
     bool maybe_fresh = true;                  /* the next sample may go to the initialiser (host-side view) */
     std::map<size_t, double *> d_power;       /* chunk length L -> A^L (N x N, row-major) on the device */
+    /* interleaved segments (orders 9..16, pipe16_kernel.hip stream mode) */
+    double *d_exch = nullptr;                 /* granules {value, generation}: 16 per segment of a call */
+    size_t exch_segments = 0;
+    unsigned long long exch_gen = 0;          /* generations handed out so far: never reused on this buffer */
+    unsigned int *h_error = nullptr;          /* pinned, device-visible: a bounded wait of the kernel ran out */
+    int interleave = 0;                       /* workgroups to deal the segments to; <= 0 = mode off (default) */
     HostPipe host;                            /* staging rings of RTFilterStream_updaten_host, built on first use */
 };
 
@@ -2457,6 +2506,63 @@ int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t
     return RTFB_OK;
 }
 
+/* Interleaved segments: the stream's 2048-sample segments dealt round-robin over one resident round of
+ * workgroups, each segment started from the zero-state end vector of the one before it (dsp_internal.h:
+ * Pipe16Ext).  For designs of order 9..16 whose decay length is at most one segment; the grid then sweeps ONE
+ * contiguous window of the stream (the access pattern of the tiled block layout) instead of 1024 windows 8 MiB
+ * apart, and no run-up launch is needed. */
+constexpr size_t kStream16MinSegments = 64;
+constexpr size_t kStream16MaxSegments = (size_t)1 << 19;      /* per launch: 128 MiB of granules */
+
+bool stream16_ok(const RTFilterStream *st)
+{
+    if (st->kind != RTFB_KIND_IIR || !st->exact_ok || !st->decay || st->decay > kPipe16Seg) return false;
+    const Group &g = st->one->groups[0];
+    return g.order > kScan2MaxOrder && g.order <= kMaxFastOrder && st->one->mode == RTFB_MODE_AUTO;
+}
+
+int stream16_piece(RTFilterStream *st, double *out, const double *in, size_t nseg, size_t *grid_used, hipStream_t s)
+{
+    if (st->exch_segments < nseg) {
+        HIP_TRY(hipStreamSynchronize(s));
+        pool_free(st->d_exch);
+        st->d_exch = nullptr;
+        st->exch_segments = 0;
+        void *p = nullptr;
+        const size_t want = std::max(nseg, (size_t)4096);
+        /* + room for the stamps of a diagnostic build (pipe16_kernel.hip: DSP_P16_STAMPS) */
+        const size_t bytes = want * 32 * sizeof(double) + (size_t)pipe_resident_round() * 2 * 16 * sizeof(unsigned long long);
+        int rc = pool_alloc(&p, bytes, st->device);
+        if (rc) return rc;
+        st->d_exch = static_cast<double *>(p);
+        st->exch_segments = want;
+        /* pool memory may hold another stream's granules with generations this one will hand out */
+        HIP_TRY(hipMemsetAsync(st->d_exch, 0, bytes, s));
+    }
+    if (!st->h_error) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&st->h_error), 64, hipHostMallocDefault));
+        *st->h_error = 0;
+    }
+    const Group &g1 = st->one->groups[0];
+    const GroupView v = view_of(st->one, g1);
+    BlockIO io;
+    io.out = out;
+    io.ld_out = 0;
+    io.in = in;
+    io.ld_in = 0;
+    io.n = nseg * kPipe16Seg;
+    io.aligned16 = 1;
+    Pipe16Ext ext;
+    ext.exch = st->d_exch;
+    ext.gen_base = st->exch_gen;
+    ext.error = st->h_error;
+    const size_t grid = std::min(std::min((size_t)st->interleave, (size_t)pipe_resident_round()), nseg);
+    HIP_TRY(launch_iir_pipe16(g1.order, v, io, ext, (int)grid, s));
+    st->exch_gen += nseg;
+    *grid_used = grid;
+    return RTFB_OK;
+}
+
 /* A^L for the homogeneous recurrence (long double, binary powering), cached on the device per L. */
 int chunk_power(RTFilterStream *st, size_t L, const double **dev)
 {
@@ -2519,6 +2625,19 @@ int stream_split_piece_exact(RTFilterStream *st, double *out, const double *in, 
     HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, gw.d_state, C, (int)ld,
                               0, 0, s));
     HIP_TRY(launch_compose_states(gm.d_state, ld, g1.d_state, gw.d_state, ld, d_M, N, (int)C, 1, s));
+    if (getenv("DSP_AMD_DEBUG_EXACT")) {
+        (void)hipDeviceSynchronize();
+        std::vector<double> hv((C - 1) * ld), hs(C * ld), hm((size_t)N * N);
+        std::vector<int32_t> hi(C);
+        (void)hipMemcpy(hv.data(), gw.d_state, hv.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs.data(), gm.d_state, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hm.data(), d_M, hm.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hi.data(), gm.d_init, hi.size() * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "EXACT C=%zu Lc=%zu M=[%g %g %g %g]\n", C, Lc, hm[0], hm[1], hm[2], hm[3]);
+        for (size_t c = 40; c < 47 && c < C - 1; ++c)
+            fprintf(stderr, "  v[%zu] = %.17g %.17g %.17g | s[%zu] = %.17g %.17g %.17g init %d\n", c, hv[c * ld], hv[c * ld + 1],
+                    hv[c * ld + 2], c, hs[c * ld], hs[c * ld + 1], hs[c * ld + 2], hi[c]);
+    }
 
     if ((rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s))) return rc;
 
@@ -2594,6 +2713,8 @@ void RTFilterStream_destroy(RTFilterStream *st)
     RTFilterBank_destroy(st->tail);
     RTFilterBank_destroy(st->one);             /* synchronises the device */
     pool_free(st->d_scratch);
+    pool_free(st->d_exch);
+    if (st->h_error) (void)hipHostFree(st->h_error);
     for (auto &kv : st->d_power) pool_free(kv.second);
     host_pipe_release(st->host);
     delete st;
@@ -2612,7 +2733,25 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
     st->last_split = 1;
     bool first = true;
     const bool overlap = in < out + n && out < in + n;
+    if (st->h_error && *st->h_error)
+        return fail(RTFB_EDEVICE, "RTFilterStream_updaten: an earlier call's workgroups waited in vain for each other (" +
+                                      std::to_string(*st->h_error) + "): the grid was not resident at once; the "
+                                      "stream's state is undefined");
+    const bool whole16 = (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0 &&
+                         (!overlap || in == out);
     while (n) {
+        if (whole16 && st->interleave > 0 && n >= kStream16MinSegments * kPipe16Seg && stream16_ok(st)) {
+            const size_t nseg = std::min(n / kPipe16Seg, kStream16MaxSegments);
+            size_t grid = 0;
+            int rc = stream16_piece(st, out, in, nseg, &grid, s);
+            if (rc) return rc;
+            if (first) st->last_split = grid;
+            first = false;
+            out += nseg * kPipe16Seg;
+            in += nseg * kPipe16Seg;
+            n -= nseg * kPipe16Seg;
+            continue;
+        }
         /* sub-chunk: at least 4 decay lengths (the run-up costs M/Lc extra) and 8192 samples */
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
@@ -2711,6 +2850,26 @@ int RTFilterStream_import_state(RTFilterStream *st, const double *pack_dev, void
 }
 
 int RTFilterStream_exact_split(const RTFilterStream *st) { return st && st->exact_ok ? 1 : 0; }
+
+int RTFilterStream_set_interleave(RTFilterStream *st, int workgroups)
+{
+    if (!st) return fail(RTFB_EINVAL, "NULL stream");
+    st->interleave = workgroups;
+    return RTFB_OK;
+}
+
+int RTFilterStream_interleaved(const RTFilterStream *st) { return st && stream16_ok(st) ? 1 : 0; }
+
+/* diagnostics (tools/stream16_race.py): the granule buffer of the last interleaved call */
+__attribute__((visibility("default"))) int RTFilterStream_debug_exchange(const RTFilterStream *st, double **ptr, size_t *segments,
+                                                                         unsigned long long *gen_end)
+{
+    if (!st) return RTFB_EINVAL;
+    *ptr = st->d_exch;
+    *segments = st->exch_segments;
+    *gen_end = st->exch_gen;
+    return RTFB_OK;
+}
 
 int RTFilterStream_zero_state(RTFilterStream *st, void *hip_stream)
 {

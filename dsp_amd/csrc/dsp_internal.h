@@ -113,6 +113,19 @@ struct PipeExt {
     unsigned int pace_fx;
 };
 
+/* The pipelined kernel for orders 9..16 (pipe16_kernel.hip).  Bank mode: one workgroup per channel, segments in
+ * time order, the carry stays in the workgroup.  STREAM mode (exch != nullptr): ONE channel whose 2048-sample
+ * segments are dealt round-robin to the grid's workgroups (workgroup w: segments w, w + G, w + 2G, ...), so that
+ * at any moment the grid sweeps one contiguous window of the stream; segment m starts from the ZERO-STATE end
+ * vector of segment m - 1, which the workgroup that owns m - 1 publishes one step ahead (granules {value,
+ * generation}, generation of segment m = gen_base + m + 1) -- exact to 2^-80 for designs whose decay length is at
+ * most one segment, the only ones the host sends here.  The grid must be resident at once. */
+struct Pipe16Ext {
+    double *exch;                          /* [segments of the call][16] granules; nullptr: bank mode              */
+    unsigned long long gen_base;
+    unsigned int *error;                   /* raised when a bounded wait ran out                                   */
+};
+
 /* launchers (kernels.hip).  Each returns the hipError_t of the launch. */
 hipError_t launch_iir_seq(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
 hipError_t launch_iir_scan(int order, const GroupView &g, const BlockIO &io, hipStream_t s);
@@ -128,6 +141,10 @@ hipError_t launch_chain_unpack(const double *records, double *state, double *fva
                                int state_ld, hipStream_t s);
 hipError_t launch_tile_rows(double *dst, const double *src, size_t ld, size_t nch, size_t n, int to_tiles,
                             hipStream_t s);
+/* orders 9..16 on whole, 16-byte aligned segments (n a multiple of 2048): bank mode (ext.exch == nullptr) or one
+ * stream dealt over `grid` workgroups (<= pipe_resident_round(), <= n / 2048) */
+hipError_t launch_iir_pipe16(int order, const GroupView &g, const BlockIO &io, const Pipe16Ext &ext, int grid,
+                             hipStream_t s);
 hipError_t launch_iir_generic(const GroupView &g, const BlockIO &io, hipStream_t s);
 /* fused second-order sections (1 .. kMaxFusedSections per channel, a0 == 1): all sections per sample in one pass */
 constexpr int kMaxFusedSections = 4;

@@ -81,7 +81,9 @@ __device__ __forceinline__ void granule_store(double *p, double value, unsigned 
     d2 v;
     v.x = value;
     v.y = __longlong_as_double((long long)(unsigned long long)gen);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    /* the trailing wait states keep whatever the compiler puts into v's registers next away from a store that
+     * may still be reading them (a hazard it covers for stores it knows, not for inline ones) */
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ unsigned int granule_gen(d2 v) { return (unsigned int)__double_as_longlong(v.y); }
 
@@ -224,12 +226,19 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
 #endif
     auto fetch = [&](int seg, d2(&pre)[kPPieces]) {
         const size_t base = (size_t)seg * kPSeg;
-        if (base >= n) return;
-        const size_t left = n - base;
+        if (!kWhole && base >= n) return;
+        const size_t left = base < n ? n - base : 0;
         const int seg_len = left < (size_t)kPSeg ? (int)left : kPSeg;
         if constexpr (kWhole) {
             static_assert(kPPieces == 16, "four base pointers x four 1 KiB offsets");
-            const double *p0 = src + (size_t)seg * seg_in + 2 * lane;   /* piece i of the lane: + i * 1024 bytes */
+            /* Past the end the same sixteen instructions are issued on one address for all lanes (the head of the
+             * channel's block: sixteen cache lines, nothing to speak of): every park below then has exactly one
+             * younger segment's worth of loads behind it, and ONE code path.  With a second path for the last
+             * segment (no younger loads, smaller counts) the compiler resolved the join of the two by COPYING the
+             * prefetch registers in front of the counted waits -- copies of registers whose loads were still in
+             * flight; orders 1 and 2, whose steps are short, then ran their last segment on stale samples now and
+             * then (tools/check_prefetch_regs.py looks for such copies in every instantiation at build time). */
+            const double *p0 = base < n ? src + (size_t)seg * seg_in + 2 * lane : src;   /* piece i of the lane: + i * 1024 bytes */
             const double *p1 = p0 + 4 * 2 * kWave, *p2 = p0 + 8 * 2 * kWave, *p3 = p0 + 12 * 2 * kWave;
             asm volatile(
                 "global_load_dwordx4 %0, %16, off nt\n\t"
@@ -356,18 +365,12 @@ iir_pipe_kernel(GroupView g, BlockIO io, PipeExt ext)
             if (it == 9) stamp(22);
             lds_barrier();                                    /* barrier 0 */
             if (it < nseg) {
-                if (it + 1 < nseg) {                          /* segment it+1's loads are younger, still flying */
+                /* the loads issued after this segment's (segment it+1, or its stand-in past the end) are younger
+                 * and may still be flying */
 #pragma unroll
-                    for (int i = 0; i < kPPieces; ++i) {
-                        park_wait(i, true, pre[i]);
-                        *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kPPieces; ++i) {
-                        park_wait(i, false, pre[i]);
-                        *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
-                    }
+                for (int i = 0; i < kPPieces; ++i) {
+                    park_wait(i, true, pre[i]);
+                    *reinterpret_cast<d2 *>(tile + i * (4 * PT * 8) + st_addr[i & 3]) = pre[i];
                 }
             }
             lds_barrier();                                    /* barrier 1 */

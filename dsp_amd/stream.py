@@ -120,6 +120,15 @@ class FilterStream:
     def exact_split(self):
         return bool(dspdll.RTFilterStream_exact_split(self._h))
 
+    # ---- interleaved segments (include/RTFilterStream.h) ----
+    @property
+    def interleaved(self):
+        return bool(dspdll.RTFilterStream_interleaved(self._h))
+
+    def set_interleave(self, workgroups):
+        """> 0: deal the stream's segments to that many workgroups (clamped to one resident round); <= 0: off (default)."""
+        _check(dspdll.RTFilterStream_set_interleave(self._h, int(workgroups)), "RTFilterStream_set_interleave")
+
     def zero_state(self, stream=None):
         _check(dspdll.RTFilterStream_zero_state(self._h, _stream_ptr(stream, self.device)), "RTFilterStream_zero_state")
 

@@ -96,6 +96,20 @@ EXPORT int RTFilterStream_zero_state(RTFilterStream *stream, void *hip_stream);
 EXPORT int RTFilterStream_compose_state(RTFilterStream *stream, const double *packs_dev, size_t stride,
                                         size_t count, size_t chunk_len, void *hip_stream);
 
+/* ---- interleaved segments (orders 9..16 whose decay length is at most 2048 samples; OFF by default) ----------
+ * An alternative to the contiguous time split for such designs: RTFilterStream_updaten deals the stream's
+ * 2048-sample segments round-robin over `workgroups` workgroups of the two-wave kernel of pipe16_kernel.hip, so
+ * that at any moment the grid works on ONE contiguous window of the stream, and each segment takes its start state
+ * from the workgroup that owns the segment in front of it (that segment's zero-state response, exact to 2^-80 like
+ * the run-up it replaces; no run-up launch).  Same results to 1e-12 (tests/test_gpu_pipe16.py); measured on MI355X it
+ * is NOT faster than the default, which is why it is opt-in.  The workgroups of such a launch wait for
+ * each other and must be resident at once: at most 4 per CU (clamped), and not beside another kernel that fills
+ * the GPU -- a wait that runs out after 2 s makes this and every later call on the stream return RTFB_EDEVICE.
+ * Device memory: 256 bytes per segment of the longest call, kept with the stream.
+ * _set_interleave: workgroups > 0 turns the mode on, <= 0 off.  _interleaved: 1 if the design qualifies. */
+EXPORT int RTFilterStream_set_interleave(RTFilterStream *stream, int workgroups);
+EXPORT int RTFilterStream_interleaved(const RTFilterStream *stream);
+
 /* Host access to the carried state (state_ld doubles, see RTFilterStream_pack_len() - 2). */
 EXPORT int RTFilterStream_get_state(RTFilterStream *stream, double *state, double *fval, int32_t *init,
                                     void *hip_stream);
