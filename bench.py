@@ -565,6 +565,11 @@ def main_fir512(args, emit=True):
         dist.destroy_process_group()
 
 
+def fv_needs_rows(args):
+    """--gather-fval reads the last column of the output rows."""
+    return bool(getattr(args, "gather_fval", False))
+
+
 def main_mixed(args, emit=True):
     """BASELINE.json config 4 as SURVEY.md 8(d) pins it: a 2^20-channel bank, channels sorted by type -- the
     first 2^19 are the 8th-order IIR of config 2, the next 2^19 a 32-tap windowed-sinc FIR -- x 65 536 samples,
@@ -615,6 +620,10 @@ def main_mixed(args, emit=True):
         order = list(range(len(banks)))
     pitch = BLOCK + 128
     gather_rows = dist is not None and args.gather
+    # --layout tiles (default): the wave's block in the tiled block layout [32 tiles][wave channels][2048]
+    # (RTFilterBank_updaten_tiled; the IIR waves go round by round on the schedule).  The row gather and
+    # the interleaved variant keep dense rows at pitch 64K + 128.
+    tiled = args.layout == "tiles" and args.mixed_layout == "sorted" and not gather_rows and fv_needs_rows(args) is False
     nybuf = 2 if gather_rows else 1                  # the gather of wave w reads y while wave w+1 is written
     xbuf = torch.empty((wave, pitch), dtype=torch.float64, device=dev)
     ybufs = [torch.empty((wave, pitch), dtype=torch.float64, device=dev) for _ in range(nybuf)]
@@ -643,7 +652,10 @@ def main_mixed(args, emit=True):
             stream.wait_event(y_free[k % nybuf])     # the gather that read this buffer two steps ago is done
         if ev is not None:
             ev[0].record(stream)
-        bank.updaten_ptr(ybuf.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
+        if tiled:
+            bank.updaten_tiled_ptr(ybuf.data_ptr(), xbuf.data_ptr(), BLOCK, stream)
+        else:
+            bank.updaten_ptr(ybuf.data_ptr(), pitch, x.data_ptr(), pitch, BLOCK, stream)
         if ev is not None:
             ev[1].record(stream)
         if fv_all is not None:
@@ -696,8 +708,12 @@ def main_mixed(args, emit=True):
         for k in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            rc = dspdll.dsp_copy_rows(C.c_void_p(ybufs[0].data_ptr()), pitch, C.c_void_p(x.data_ptr()), pitch, wave, BLOCK,
-                                      256, 8192, C.c_void_p(stream.cuda_stream))
+            if tiled:
+                rc = dspdll.dsp_copy_tiles(C.c_void_p(ybufs[0].data_ptr()), C.c_void_p(xbuf.data_ptr()), wave, BLOCK,
+                                           C.c_void_p(stream.cuda_stream))
+            else:
+                rc = dspdll.dsp_copy_rows(C.c_void_p(ybufs[0].data_ptr()), pitch, C.c_void_p(x.data_ptr()), pitch, wave,
+                                          BLOCK, 256, 8192, C.c_void_p(stream.cuda_stream))
             e1.record(stream)
             torch.cuda.synchronize()
             if rc == 0 and k >= 1:
@@ -720,7 +736,9 @@ def main_mixed(args, emit=True):
                                                  if args.mixed_layout == "sorted" else
                                                  "IIR 8 / IIR 16 / FIR 32 / IIR 5 interleaved", wave),
                        "channels_per_gpu": per_rank, "wave_channels": wave, "waves_per_gpu": nwaves, "block": BLOCK,
-                       "row_pitch_doubles": pitch, "kernel": args.mode,
+                       "layout": ("tiles: every wave's block stored [32 tiles][%d channels][2048 samples], "
+                                  "RTFilterBank_updaten_tiled" % wave) if tiled else "dense rows",
+                       "row_pitch_doubles": gbank.TILE if tiled else pitch, "kernel": args.mode,
                        "gather": "rows" if gather_rows else ("filtered_value" if fv_all is not None else None),
                        "rank0_wave_ms": {k: float(np.mean(v)) for k, v in per_kind.items()},
                        "parallelism": "channel-sharded x%d" % world},
@@ -729,7 +747,9 @@ def main_mixed(args, emit=True):
                          "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
                          "copy_ceiling_measured": copy_gbs,
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "note": "all kernels of one RTFilterBank_updaten over one wave, rank 0's device time per call",
+                         "note": "all kernels of one RTFilterBank_updaten%s over one wave, rank 0's device time per "
+                                 "call; copy ceiling = the row-per-workgroup copy twin in the same layout (unpaced)"
+                                 % ("_tiled" if tiled else ""),
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         if gather_rows and g_events:

@@ -2024,14 +2024,63 @@ static int pipe_block(const RTFilterBank *bank, double *out, size_t ld_out, cons
     return RTFB_OK;
 }
 
+/* FIR banks in the tiled block layout: ONE launch group that the matrix-core kernel serves with every head folded
+ * (stable_init designs of 2..2047 taps, not RTFB_MODE_SEQUENTIAL), n a multiple of 4096.  Same results as
+ * RTFilterBank_updaten on the same blocks (same kernel arithmetic); not paced (fir_kernels.hip: why). */
+
+static int fir_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream)
+{
+    const char *what = "the tiled block layout is served by the pipelined IIR kernel (one launch group of order <= 8, "
+                       "<= 1024 designs, scan-safe or RTFB_MODE_SCAN) and by the matrix-core FIR kernel (one launch "
+                       "group of stable_init designs with 2..2047 taps, n a multiple of 4096, not "
+                       "RTFB_MODE_SEQUENTIAL)";
+    if (bank->groups.size() != 1 || bank->groups[0].cls != kFir || bank->mode == RTFB_MODE_SEQUENTIAL)
+        return fail(RTFB_EUNSUPPORTED, what);
+    Group &g = bank->groups[0];
+    DeviceScope ds(bank->device);
+    if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16) != 0)
+        return fail(RTFB_EINVAL, "in / out must be 16-byte aligned");
+    GroupView v = view_of(bank, g);
+    v.fir_mfma = g.kmax >= kFirMfmaMinTaps ? 1 : 0;
+    if (!fir_tiled_supported(v, n)) return fail(n % 4096 ? RTFB_ESIZE : RTFB_EUNSUPPORTED, what);
+    int rc = chain_close(bank, s);
+    if (rc) return rc;
+    BlockIO io;
+    io.out = out;
+    io.in = in;
+    io.ld_in = io.ld_out = RTFB_TILE;
+    io.n = n;
+    io.aligned16 = 1;
+    const size_t seg = bank->nch * (size_t)RTFB_TILE, total = bank->nch * n;
+    if (in == out) {
+        /* FIR outputs are produced out of time order: an in-place call reads from a private copy (same layout) */
+        if (g.scratch_doubles < total) {
+            HIP_TRY(hipStreamSynchronize(s));
+            pool_free(g.d_scratch);
+            g.d_scratch = nullptr;
+            g.scratch_doubles = 0;
+            void *p = nullptr;
+            rc = pool_alloc(&p, total * sizeof(double), bank->device);
+            if (rc) return rc;
+            g.d_scratch = static_cast<double *>(p);
+            g.scratch_doubles = total;
+        }
+        HIP_TRY(hipMemcpyAsync(g.d_scratch, in, total * sizeof(double), hipMemcpyDeviceToDevice, s));
+        io.in = g.d_scratch;
+    } else if (in < out + total && out < in + total)
+        return fail(RTFB_EINVAL, "RTFilterBank_updaten_tiled: in and out overlap without being equal");
+    HIP_TRY(launch_fir_tiled(v, io, seg, seg, s));
+    return RTFB_OK;
+}
+
 int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream)
 {
     if (!bank || !out || !in) return fail(RTFB_EINVAL, "RTFilterBank_updaten_tiled: NULL argument");
     if (n == 0) return RTFB_OK;
     Group *g = chain_group(bank);
-    if (!g)
-        return fail(RTFB_EUNSUPPORTED, "the tiled block layout is served by the pipelined IIR kernel only: one launch "
-                                       "group of order <= 8, <= 1024 designs, scan-safe (or RTFB_MODE_SCAN)");
+    if (!g) return fir_updaten_tiled(bank, out, in, n, hip_stream);
     DeviceScope ds(bank->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -2041,14 +2090,16 @@ int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in
     if (rc || (rc = chain_close(bank, s))) return rc;
     const GroupView v = view_of(bank, *g);
     const int round = pipe_resident_round();
-    ext.pace_fx = pace_period(*g, v.count, n, round);
-    /* a group a little wider than one resident round goes round by round, as in launch_pipe_n */
-    const int step = (v.count > round && v.count <= 4 * round) ? round : v.count;
+    /* A group wider than one resident round goes round by round: in this layout the workgroups of ONE round sweep
+     * one contiguous window per step, a launch several rounds deep would put workgroups of different segments (a
+     * whole [nch][2048] slab apart) next to each other. */
+    const int step = v.count > round ? round : v.count;
     for (int off = 0; off < v.count; off += step) {
         GroupView h = v;
         h.chan = v.chan ? v.chan + off : nullptr;
         h.chan0 = v.chan0 + off;
         h.count = std::min(step, v.count - off);
+        ext.pace_fx = pace_period(*g, h.count, n, round);
         h.design = v.design + off;
         h.state = v.state + (size_t)off * v.state_ld;
         h.fval = v.fval + off;

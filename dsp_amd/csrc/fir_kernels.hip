@@ -694,7 +694,9 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
 
 /* One steady item: kMfmaSeg outputs of one channel with the whole window inside the block. */
 struct MfmaItem {
-    const double *x0;       /* input of the first staged element: x + seg_base - hist */
+    const double *x0;       /* input of the first staged element: x + seg_base - hist (tiled block layout: the
+                               channel's first tile, staged element e = sample p0 + e of the block) */
+    int p0;                 /* tiled block layout only: seg_base - hist */
     int emax;               /* last staged element that exists (the 16 look-ahead samples of the block's
                                last segment do not: they repeat x[n-1] and only ever meet zero taps) */
     double *out;            /* out + seg_base */
@@ -712,6 +714,7 @@ struct MfmaItem {
 };
 
 
+template <bool kTiled = false>
 __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO &io, int gi, int seg,
                                               long long head_out, long long ramp_first, bool fold)
 {
@@ -723,10 +726,20 @@ __device__ __forceinline__ MfmaItem mfma_item(const GroupView &g, const BlockIO 
     it.steps = mfma_steps16(it.K);                  /* delta = -12 + 16 o + 4 u, o < steps */
     it.hist = 16 * (it.steps - 1);                  /* inputs staged before seg_base (>= K-1) */
     const long long seg_base = (long long)seg * kMfmaSeg;
-    it.x0 = io.in + (size_t)chan * io.ld_in + (seg_base - it.hist);
     const long long last = (long long)io.n - 1 - (seg_base - it.hist);
-    it.emax = last < it.hist + kMfmaSeg + 15 ? (int)last : it.hist + kMfmaSeg + 15;
-    it.out = io.out + (size_t)chan * io.ld_out + seg_base;
+    if constexpr (kTiled) {
+        /* [n / 2048][nch][2048], io.ld_* = 2048: x0 / out are the channel's rows in the first tile; the 16
+         * look-ahead samples (which only ever meet zero taps) are never fetched from the next tile */
+        it.x0 = io.in + (size_t)chan * io.ld_in;
+        it.p0 = (int)(seg_base - it.hist);
+        it.emax = it.hist + kMfmaSeg - 1;
+        it.out = io.out + (size_t)chan * io.ld_out;
+    } else {
+        it.x0 = io.in + (size_t)chan * io.ld_in + (seg_base - it.hist);
+        it.p0 = 0;
+        it.emax = last < it.hist + kMfmaSeg + 15 ? (int)last : it.hist + kMfmaSeg + 15;
+        it.out = io.out + (size_t)chan * io.ld_out + seg_base;
+    }
     it.st = g.state + (size_t)gi * g.state_ld;
     it.tail = as_const(it.st)[it.K - 1];            /* written by an earlier kernel */
     it.emin = seg_base < it.hist ? (int)(it.hist - seg_base) : 0;
@@ -764,11 +777,20 @@ __device__ __forceinline__ void mfma_store(const d4 (&acc)[kMfmaTiles], double *
  * registers before the contraction of the current one starts, so the global latency sits under
  * ~34k cycles of MFMA work instead of in front of it.  No guards anywhere: all loads of a thread
  * are in flight together and nothing makes the compiler drain vmcnt inside the item loop. */
-template <bool kAligned16>
+/* kTiled: the tiled block layout [n / 2048][nch][2048] (RTFilterBank_updaten_tiled; aligned, n a multiple of the
+ * item, every head folded).  seg_in / seg_out = doubles between consecutive tiles of a channel.  Workgroup w takes
+ * channels w, w + grid, w + 2 grid, ... and walks each through its items in time order, so that the workgroups of
+ * the grid, as long as they are in step, sweep ONE window of grid x 32 KiB per item instead of grid rows a pitch
+ * apart (the reason the layout exists).  No schedule here: holding the prefetch of item k + 1 back until
+ * launch start + (k + 1) x period, as the pipelined IIR kernel does, was measured on 65 536 x 64K at 32 taps with
+ * periods from 5.3 to 6.2 TB/s and never engages -- a workgroup's own item loop (three per CU) sustains 5.1 TB/s
+ * at most, every workgroup is late at once and runs free. */
+template <bool kAligned16, bool kTiled = false>
 __global__ void __launch_bounds__(kMfmaWaves * kWave, 3)      /* 3 waves per SIMD: <= 168 VGPRs */
 fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long head_out, long long ramp_first,
-                int fold)
+                int fold, size_t seg_in, size_t seg_out)
 {
+    static_assert(!kTiled || kAligned16, "the tiled block layout is 16-byte aligned by construction");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *lds = reinterpret_cast<double *>(smem_raw);
     constexpr int kThreads = kMfmaWaves * kWave;
@@ -779,13 +801,22 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
     const int j = lane & 15, q = lane >> 4;
     const int nseg = steady_hi - steady_lo;
     const long long items = (long long)nseg * g.count;
-    long long idx = items * blockIdx.x / gridDim.x;
-    const long long idx_end = items * (blockIdx.x + 1) / gridDim.x;
+    long long idx = kTiled ? 0 : items * blockIdx.x / gridDim.x;
+    const long long idx_end = kTiled ? (long long)nseg * ((g.count - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x)
+                                     : items * (blockIdx.x + 1) / gridDim.x;
     if (idx >= idx_end) return;
-    int gi = (int)(idx / nseg);
-    int seg = (int)(idx - (long long)gi * nseg);
+    int gi = kTiled ? (int)blockIdx.x : (int)(idx / nseg);
+    int seg = kTiled ? 0 : (int)(idx - (long long)gi * nseg);
+    /* staged element e of an item */
+    auto xptr = [&](const MfmaItem &it, int e) -> const double * {
+        if constexpr (kTiled) {
+            const int p = it.p0 + e;
+            return it.x0 + (size_t)(p >> 11) * seg_in + (p & 2047);
+        } else
+            return it.x0 + e;
+    };
 
-    MfmaItem cur = mfma_item(g, io, gi, steady_lo + seg, head_out, ramp_first, kAligned16 && fold != 0);
+    MfmaItem cur = mfma_item<kTiled>(g, io, gi, steady_lo + seg, head_out, ramp_first, kAligned16 && fold != 0);
     /* emax is odd here (hist + 4096 - 1 when the block ends with the item, else hist + 4096 + 15), so a pair
      * clamped to emax >> 1 never reaches past it; clamped positions only ever meet zero taps */
     double xr[kMfmaPre];
@@ -794,10 +825,10 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
         if constexpr (kAligned16) {
 #pragma unroll
             for (int k = 0; k < kMfmaPre2; ++k)
-                xr2[k] = *reinterpret_cast<const d2 *>(it.x0 + 2 * max(min(tid + kThreads * k, it.emax >> 1), it.emin >> 1));
+                xr2[k] = *reinterpret_cast<const d2 *>(xptr(it, 2 * max(min(tid + kThreads * k, it.emax >> 1), it.emin >> 1)));
         } else {
 #pragma unroll
-            for (int k = 0; k < kMfmaPre; ++k) xr[k] = it.x0[max(min(tid + kThreads * k, it.emax), it.emin)];
+            for (int k = 0; k < kMfmaPre; ++k) xr[k] = *xptr(it, max(min(tid + kThreads * k, it.emax), it.emin));
         }
     };
     prefetch(cur);
@@ -829,7 +860,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
                 for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
             }
             for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
-                xs[xpos(e)] = cur.x0[max(min(e, cur.emax), cur.emin)];
+                xs[xpos(e)] = *xptr(cur, max(min(e, cur.emax), cur.emin));
         } else {
             /* The block's first item: zeros where there is no regular sample (before t0), nothing written past
              * the item's inputs, and the state loaded here, where the prefetch registers are free again -- the
@@ -852,10 +883,10 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
                 }
             }
             for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads) {
-                const double v = cur.x0[max(min(e, cur.emax), cur.emin)];
+                const double v = *xptr(cur, max(min(e, cur.emax), cur.emin));
                 xs[xpos(e)] = e < zmin ? 0.0 : v;
             }
-            for (int e = tid; e < cur.K; e += kThreads) sa[e] = (e == 0 ? cur.x0[cur.hist] : cur.st[e - 1]) - cur.tail;
+            for (int e = tid; e < cur.K; e += kThreads) sa[e] = (e == 0 ? *xptr(cur, cur.hist) : cur.st[e - 1]) - cur.tail;
         }
         if (cur.dsn != staged_dsn) {
             for (int e = tid; e < nb_pad; e += kThreads) {
@@ -876,19 +907,25 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
         const long long lead = cur.first - seg_base - 256 * kMfmaTiles * wave;
         const int cur_skip = lead <= 0 ? 0 : (lead >= 256 * kMfmaTiles ? kMfmaTiles : (int)(lead >> 8));
         MfmaItem nxt = cur;
+        const long long cur_base = seg_base;
         if (idx + 1 < idx_end) {
             if (++seg == nseg) {                                /* next channel: a chain of scalar loads */
                 seg = 0;
-                ++gi;
-                nxt = mfma_item(g, io, gi, steady_lo, head_out, ramp_first, kAligned16 && fold != 0);
+                gi += kTiled ? (int)gridDim.x : 1;
+                nxt = mfma_item<kTiled>(g, io, gi, steady_lo, head_out, ramp_first, kAligned16 && fold != 0);
             } else {                                            /* next segment of the same channel */
                 nxt.head = false;
-                nxt.x0 += kMfmaSeg;
-                nxt.out += kMfmaSeg;
                 const long long nb = (long long)(steady_lo + seg) * kMfmaSeg;
-                const long long last = (long long)io.n - 1 - (nb - cur.hist);
-                nxt.emax = last < cur.hist + kMfmaSeg + 15 ? (int)last : cur.hist + kMfmaSeg + 15;
-                nxt.emin = nb < cur.hist ? (int)(cur.hist - nb) : 0;
+                if constexpr (kTiled) {
+                    nxt.p0 += kMfmaSeg;
+                    nxt.emin = 0;                               /* hist <= 2048 < one item */
+                } else {
+                    nxt.x0 += kMfmaSeg;
+                    nxt.out += kMfmaSeg;
+                    const long long last = (long long)io.n - 1 - (nb - cur.hist);
+                    nxt.emax = last < cur.hist + kMfmaSeg + 15 ? (int)last : cur.hist + kMfmaSeg + 15;
+                    nxt.emin = nb < cur.hist ? (int)(cur.hist - nb) : 0;
+                }
             }
             seg_base = (long long)(steady_lo + seg) * kMfmaSeg;
             prefetch(nxt);
@@ -949,7 +986,10 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
             }
         }
 
-        pending = cur.out + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
+        if constexpr (kTiled)       /* wavefronts 0, 1: the item's first tile of 2048 outputs; 2, 3: its second */
+            pending = cur.out + (size_t)((cur_base >> 11) + (wave >> 1)) * seg_out + 256 * kMfmaTiles * (wave & 1) + 16 * j + 4 * q;
+        else
+            pending = cur.out + 256 * kMfmaTiles * wave + 16 * j + 4 * q;
         pending_skip = cur_skip;
         cur = nxt;
     }
@@ -960,7 +1000,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
 static int mfma_resident_groups(size_t lds_bytes)
 {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fir_mfma_kernel<true>, kMfmaWaves * kWave, lds_bytes) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fir_mfma_kernel<true, false>, kMfmaWaves * kWave, lds_bytes) !=
             hipSuccess || per_cu < 1)
         per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1269,11 +1309,13 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
             long long grid = mfma_resident_groups(mfma_lds);
             if (grid > items) grid = items;
             if (io.aligned16)
-                hipLaunchKernelGGL(fir_mfma_kernel<true>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0);
+                hipLaunchKernelGGL((fir_mfma_kernel<true, false>), dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0,
+                                   (size_t)0, (size_t)0);
             else
-                hipLaunchKernelGGL(fir_mfma_kernel<false>, dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
-                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0);
+                hipLaunchKernelGGL((fir_mfma_kernel<false, false>), dim3((unsigned)grid), dim3(kMfmaWaves * kWave),
+                                   mfma_lds, s, g, io, steady_lo, steady_hi, head_out, ramp_first, fold ? 1 : 0,
+                                   (size_t)0, (size_t)0);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
@@ -1298,6 +1340,45 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
     }
     const size_t epi_lds = (size_t)(g.kmax + (g.kmax + kEpiR) + (g.kmax + kEpiR) / kEpiR + 2) * sizeof(double);
     hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(kEpiThreads), epi_lds, s, g, io);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_fir_commit(g, s);
+}
+
+/* The tiled block layout [n / 2048][nch][2048] for a group the matrix-core kernel serves with every head folded
+ * (no partial_init channels, 2 <= K <= 2047) and n a multiple of the 4096-output item: prologue (sample 0 of a
+ * reset stream sits at the same place in both layouts), ONE persistent launch, the end state from the block's last
+ * tile (it holds the K-1 samples the state depends on) and the commit.  io.ld_* = 2048. */
+bool fir_tiled_supported(const GroupView &g, size_t n)
+{
+    return g.fir_mfma && !g.has_partial && g.kmax >= 2 && g.kmax <= 2047 && n > 0 && n % kMfmaSeg == 0 &&
+           n <= ((size_t)1 << 30);
+}
+
+hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, hipStream_t s)
+{
+    const int pro_blocks = (g.count + 255) / 256;
+    hipLaunchKernelGGL(fir_prologue_kernel, dim3(pro_blocks), dim3(256), 0, s, g, io);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int hist = 16 * (mfma_steps16(g.kmax) - 1);
+    int xtotal = hist + kMfmaSeg + 16;
+    if (xtotal < kMfmaPreElems) xtotal = kMfmaPreElems;
+    size_t mfma_lds = (size_t)(hist + 32 + xtotal + 2 * (xtotal >> 4) + 2) * sizeof(double);
+    const int ptotal = hist + kMfmaSeg + 16;
+    const size_t with_state = (size_t)(hist + 32 + ptotal + 2 * (ptotal >> 4) + 2 + g.kmax) * sizeof(double);
+    if (with_state > mfma_lds) mfma_lds = with_state;
+    long long grid = mfma_resident_groups(mfma_lds);
+    if (grid > g.count) grid = g.count;
+    hipLaunchKernelGGL((fir_mfma_kernel<true, true>), dim3((unsigned)grid), dim3(kMfmaWaves * kWave), mfma_lds, s, g, io,
+                       0, (int)(io.n / kMfmaSeg), 0LL, 0LL, 1, seg_in, seg_out);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    BlockIO last = io;                                          /* the block's last tile as a block of its own */
+    last.in = io.in + (io.n / 2048 - 1) * seg_in;
+    last.out = io.out + (io.n / 2048 - 1) * seg_out;
+    last.n = 2048;
+    const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
+    const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
+    hipLaunchKernelGGL(fir_epilogue_taps_kernel, dim3(passes, g.count), dim3(kWave), lds_taps, s, g, last);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return launch_fir_commit(g, s);
 }

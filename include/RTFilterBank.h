@@ -162,7 +162,14 @@ EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
  * The workgroups that run together then sweep one contiguous window of HBM per step instead of nch streams a row
  * pitch apart (measured on the copy twin: 5.9 vs 5.45 TB/s at 1024 x 64K, profiles/r3_tiled_copy.txt).  in == out
  * is allowed.  dsp_tile_rows / dsp_untile_rows convert between rows (pitch ld) and tiles on the device.
- * Other banks: RTFB_EUNSUPPORTED. */
+ * Banks wider than the workgroups the GPU holds at once (1024 on MI355X) are launched round by round, 1024
+ * channels each: 65 536 x 64K runs at 5.56 TB/s where dense rows give 5.24 (profiles/r3_config4_tiled.txt).
+ * _updaten_tiled (not the chained entry) also serves FIR banks: ONE launch group of RTFB_KIND_FIR designs
+ * (stable_init) with 2..2047 taps, any mode but RTFB_MODE_SEQUENTIAL, n a multiple of 2 RTFB_TILE; the
+ * matrix-core kernel then walks the tiles (workgroup w: channels w, w + grid, ...) -- the bits of
+ * RTFilterBank_updaten in the same mode, a gain of 2 % only (that kernel is not bound by the address pattern),
+ * there so that a bank of either kind can live in one layout.  in == out or disjoint.
+ * Other banks: RTFB_EUNSUPPORTED; a block length that does not fit: RTFB_ESIZE. */
 #define RTFB_TILE 2048
 EXPORT int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream);
 /* The tiled layout pays while the workgroups of a launch stay in step, so tiled launches of banks that fill the GPU

@@ -156,3 +156,100 @@ def test_chain_then_reset_then_chain(G):
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("nch,ntiles", [(2500, 12), (4500, 3)])
+def test_tiled_wide_bank_round_by_round_matches_rows_to_the_bit(G, nch, ntiles):
+    """Banks wider than one resident round of workgroups: the tiled entry launches them round by round (full
+    rounds of >= 12 tiles on the schedule), two blocks with the state carried."""
+    import torch
+    from dsp_amd import bank as gbank
+    key, n = "bw4_bp_0.3_0.6", ntiles * gbank.TILE
+    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    for i in range(2):
+        x = torch.empty((nch, n), dtype=torch.float64, device="cuda")
+        gbank.synth_fill(x, 0x5EED0002, chan0=0, n0=i * n)
+        want = a_bank(x)
+        xt = gbank.tile_rows(x)
+        yt = torch.empty_like(xt)
+        b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        assert torch.equal(gbank.untile_rows(yt), want), i
+    for p, q in zip(a_bank.get_state(), b_bank.get_state()):
+        assert util.bits_equal(p, q)
+    # against the oracle: a few channels of the second block's end state would need the whole run; the rows entry
+    # is held to the oracle at this shape in test_gpu_iir / test_gpu_fullsize, and the outputs above are its bits
+
+
+@pytest.mark.parametrize("key,nch", [("fir32_lp_0.25", 40), ("fir7_lp_0.4", 17), ("fir7_lp_0.4", 1), ("fir512_lp_0.25", 6)])
+def test_tiled_fir_matches_rows(G, key, nch):
+    """FIR banks on the tiled layout (matrix-core kernel, every head folded): blocks of 2, 4 and 2 tiles, the first
+    on a fresh stream (stable_init), the last in place.  Same kernel arithmetic as RTFilterBank_updaten in AUTO
+    mode: equal bits, the carried delay line included; and the bit-exact mode / oracle within 1e-12."""
+    import torch
+    from dsp_amd import bank as gbank
+    blocks = [2 * gbank.TILE, 4 * gbank.TILE, 2 * gbank.TILE]
+    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    pos, ys = 0, []
+    for i, n in enumerate(blocks):
+        x = G.to_dev(G.make_inputs(78, nch, n, pos))
+        want = a_bank(x)
+        xt = gbank.tile_rows(x)
+        yt = xt if i == 2 else torch.empty_like(xt)
+        b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        got = gbank.untile_rows(yt)
+        assert torch.equal(got, want), (key, i)
+        ys.append(got.cpu().numpy())
+        pos += n
+    for p, q in zip(a_bank.get_state(), b_bank.get_state()):
+        assert util.bits_equal(p, q)
+    want_o, ob = _oracle_rows(G, key, G.make_inputs(78, nch, sum(blocks), 0))
+    assert util.rel_to_peak(np.concatenate(ys, axis=1), want_o).max() <= TOL
+    assert util.bits_equal(b_bank.get_state()[0][:, :ob.state.shape[1]], ob.state)     # bit-exact end-state kernels
+
+
+def test_tiled_fir_wide_bank(G):
+    """More channels than four grids of the persistent kernel: workgroup w walks channels w, w + grid, w + 2 grid ...
+    Against the rows entry (bits) and the oracle on sampled channels."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    key, nch, n = "fir32_lp_0.25", 3400, 2 * gbank.TILE
+    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    outs = []
+    for i in range(2):
+        x = torch.empty((nch, n), dtype=torch.float64, device="cuda")
+        gbank.synth_fill(x, 0x5EED0004, chan0=0, n0=i * n)
+        want = a_bank(x)
+        xt = gbank.tile_rows(x)
+        yt = torch.empty_like(xt)
+        b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        got = gbank.untile_rows(yt)
+        assert torch.equal(got, want), i
+        outs.append(got)
+    for p, q in zip(a_bank.get_state(), b_bank.get_state()):
+        assert util.bits_equal(p, q)
+    d = G.to_orc_design(G.golden_design(key))
+    for c in (0, 767, 768, 3399):
+        xin = util.synth(0x5EED0004, c, 0, 2 * n)
+        want_o = orc.Bank([d], [0]).updaten(xin[None, :], threads=1)[0]
+        got = torch.cat([o[c] for o in outs]).cpu().numpy()
+        assert util.rel_to_peak(got, want_o) <= TOL, c
+
+
+def test_tiled_entry_refuses_what_it_does_not_serve(G):
+    import torch
+    from dsp_amd import bank as gbank
+    x = torch.zeros((4, 2 * gbank.TILE), dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    fir = _bank(G, "fir32_lp_0.25", 4)
+    with pytest.raises(Exception):                          # one tile: not a multiple of the 4096-output item
+        fir.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), gbank.TILE)
+    seq = _bank(G, "fir32_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)
+    with pytest.raises(Exception):
+        seq.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
+    _, b, _ = util.design_coefs("mavg32")
+    ramp = gbank.FilterBank([gbank.fir_design(b, partial=True)], [0] * 4)
+    with pytest.raises(Exception):
+        ramp.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
+    assert np.all(fir.get_state()[2] != 0)                  # nothing was enqueued: every channel is still fresh
+    assert torch.all(fir(x) == 0)                           # and the bank still works
