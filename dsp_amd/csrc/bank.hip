@@ -1306,7 +1306,7 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
         if ((rc = upload(&g.d_state, st, device))) return rc;
         if (g.cls == kFir) {
             if ((rc = upload(&g.d_state_alt, st, device))) return rc;
-            std::vector<int32_t> aux(2 * cnt, 0);
+            std::vector<int32_t> aux(4 * cnt + 2, 0);      /* + a 64-bit word per channel and one int (fir_kernels.hip: nf_mark) */
             if ((rc = upload(&g.d_aux, aux, device))) return rc;
         }
         if (g.cls == kIirFast && std::getenv("DSP_AMD_SCAN_STAMPS")) {   /* diagnostics only */

@@ -40,6 +40,35 @@ constexpr int S = kFirSeg;
  * stride of T = 32 doubles fall on distinct banks. */
 __device__ __forceinline__ int skew(int e) { return e + (e >> 5); }
 
+/* g.aux: 2 ints per channel (prologue -> main / epilogue), then one 64-bit word per channel -- bit (item & 63) set
+ * when the matrix-core kernels staged a non-finite sample for that 4096-output item -- then one int, nonzero when
+ * any word is. */
+__device__ __forceinline__ unsigned long long *nf_dirty(const GroupView &g)
+{
+    return reinterpret_cast<unsigned long long *>(g.aux + 2 * (size_t)g.count);
+}
+__device__ __forceinline__ int *nf_any(const GroupView &g) { return g.aux + 4 * (size_t)g.count; }
+__device__ __forceinline__ void nf_mark(const GroupView &g, int gi, int item)
+{
+    atomicOr(nf_dirty(g) + gi, 1ull << (item & 63));
+    atomicOr(nf_any(g), 1);
+}
+/* Is an Inf / NaN among the values a thread staged?  On the integer side (an FP64 compare per sample runs at the
+ * matrix cores' expense): a double is non-finite iff its high word without the sign is >= 0x7FF00000; two running
+ * maxima of the high words, one v_max3 each per pair of samples. */
+struct NfKey {
+    unsigned u = 0;     /* unsigned maximum: >= 0xFFF00000 iff a -Inf / negative NaN was among them */
+    int s = 0;          /* signed maximum:   >= 0x7FF00000 iff a +Inf / positive NaN was */
+    __device__ __forceinline__ void add(double a, double b)
+    {
+        const int ha = __double2hiint(a), hb = __double2hiint(b);
+        u = max(max(u, (unsigned)ha), (unsigned)hb);
+        s = max(max(s, ha), hb);
+    }
+    __device__ __forceinline__ void add(double a) { add(a, a); }
+    __device__ __forceinline__ bool odd() const { return u >= 0xFFF00000u || s >= 0x7FF00000; }
+};
+
 }  // namespace
 
 __global__ void __launch_bounds__(256)
@@ -76,6 +105,8 @@ fir_prologue_kernel(GroupView g, BlockIO io)
     }
     g.aux[2 * gi] = t0;
     g.aux[2 * gi + 1] = ramp0;
+    nf_dirty(g)[gi] = 0ull;                      /* items of this block that staged an Inf / NaN (matrix-core path) */
+    if (gi == 0) *nf_any(g) = 0;
 }
 
 /* kHead: the segment may contain outputs that still draw on the carried state
@@ -497,7 +528,11 @@ fir_epilogue_taps_kernel(GroupView g, BlockIO io)
 /* every FIR channel on the bit-exact VALU kernel above.  Head segments, the    */
 /* prologue and the epilogue (state) are shared with that kernel.  Non-finite   */
 /* inputs: the zero taps of the padding multiply up to 15 samples either side   */
-/* of a tile, so an Inf/NaN sample also poisons up to 15 earlier outputs here.   */
+/* of a tile (0 x Inf = NaN in outputs the sample never reaches in the           */
+/* reference), so an item that staged an Inf / NaN marks itself in a per-channel */
+/* word and fir_nf_fixup_kernel, launched behind the contraction kernels,        */
+/* computes such items again with the reference's own sums (oldest tap first):   */
+/* their outputs are then the reference's bits, non-finite ones included.        */
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -602,6 +637,7 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
     /* samples before t0 were consumed by stable_init (or do not exist): they feed nothing.  The loads are
      * unconditional on a clamped index and the guard is a select afterwards: guarded loads compile to a branch
      * each and wait one by one (this kernel ran at half the bandwidth of the steady one). */
+    NfKey key;
     {
         constexpr int kThreads = kMfmaWaves * kWave;
         double xr[kMfmaPre];
@@ -615,22 +651,28 @@ fir_mfma_edge_kernel(GroupView g, BlockIO io, long long ramp_first, int steady_l
 #pragma unroll
             for (int k = 0; k < kMfmaPre; ++k) {            /* LDS holds kMfmaPreElems >= 19 * 256 inputs */
                 const long long idx = seg_base - hist + tid + kThreads * k;
-                xs[xpos(tid + kThreads * k)] = (idx >= t0 && idx < n) ? xr[k] : 0.0;
+                const double v = (idx >= t0 && idx < n) ? xr[k] : 0.0;
+                key.add(v);
+                xs[xpos(tid + kThreads * k)] = v;
             }
         } else {                                            /* short head: only what its tiles read */
             for (int e = tid; e < total; e += kThreads) {
                 long long idx = seg_base - hist + e;
                 const bool ok = idx >= t0 && idx < n;
                 idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
-                const double v = x[idx];
-                xs[xpos(e)] = ok ? v : 0.0;
+                const double v = ok ? x[idx] : 0.0;
+                key.add(v);
+                xs[xpos(e)] = v;
             }
         }
         for (int e = tid + kThreads * kMfmaPre; span == kMfmaSeg && e < total; e += kThreads) {     /* very long filters */
             const long long idx = seg_base - hist + e;
-            xs[xpos(e)] = (idx >= t0 && idx < n) ? x[idx] : 0.0;
+            const double v = (idx >= t0 && idx < n) ? x[idx] : 0.0;
+            key.add(v);
+            xs[xpos(e)] = v;
         }
     }
+    if (__builtin_amdgcn_ballot_w64(key.odd()) && lane == 0) nf_mark(g, gi, seg);   /* fir_nf_fixup_kernel redoes the item */
     __syncthreads();
     if (256 * NT * wave >= span) return;                    /* this wavefront's tiles all lie past the stop */
 
@@ -850,17 +892,26 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
 
         lds_barrier();                                        /* the previous item's operand reads are over */
         /* (first, so that the wait is for the prefetch only: the previous item's stores are younger) */
+        NfKey key;                      /* Inf / NaN among the staged samples: the item is done again, see nf_mark */
         if (!cur.head) {
             if constexpr (kAligned16) {
 #pragma unroll
-                for (int k = 0; k < kMfmaPre2; ++k)        /* elements 2p, 2p+1 share a 16-group: one 16-byte write */
+                for (int k = 0; k < kMfmaPre2; ++k) {      /* elements 2p, 2p+1 share a 16-group: one 16-byte write */
                     *reinterpret_cast<d2 *>(xs + xpos(2 * (tid + kThreads * k))) = xr2[k];
+                    key.add(xr2[k].x, xr2[k].y);
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < kMfmaPre; ++k) xs[xpos(tid + kThreads * k)] = xr[k];
+                for (int k = 0; k < kMfmaPre; ++k) {
+                    xs[xpos(tid + kThreads * k)] = xr[k];
+                    key.add(xr[k]);
+                }
             }
-            for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads)   /* very long filters */
-                xs[xpos(e)] = *xptr(cur, max(min(e, cur.emax), cur.emin));
+            for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads) {   /* very long filters */
+                const double v = *xptr(cur, max(min(e, cur.emax), cur.emin));
+                key.add(v);
+                xs[xpos(e)] = v;
+            }
         } else {
             /* The block's first item: zeros where there is no regular sample (before t0), nothing written past
              * the item's inputs, and the state loaded here, where the prefetch registers are free again -- the
@@ -873,18 +924,23 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
                     d2 v = xr2[k];
                     v.x = e < zmin ? 0.0 : v.x;
                     v.y = e + 1 < zmin ? 0.0 : v.y;
+                    key.add(v.x, v.y);
                     if (e < total) *reinterpret_cast<d2 *>(xs + xpos(e)) = v;      /* total is even */
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < kMfmaPre; ++k) {
                     const int e = tid + kThreads * k;
-                    if (e < total) xs[xpos(e)] = e < zmin ? 0.0 : xr[k];
+                    const double v = e < zmin ? 0.0 : xr[k];
+                    key.add(v);
+                    if (e < total) xs[xpos(e)] = v;
                 }
             }
             for (int e = tid + kThreads * (kAligned16 ? 2 * kMfmaPre2 : kMfmaPre); e < total; e += kThreads) {
-                const double v = *xptr(cur, max(min(e, cur.emax), cur.emin));
-                xs[xpos(e)] = e < zmin ? 0.0 : v;
+                double v = *xptr(cur, max(min(e, cur.emax), cur.emin));
+                v = e < zmin ? 0.0 : v;
+                key.add(v);
+                xs[xpos(e)] = v;
             }
             for (int e = tid; e < cur.K; e += kThreads) sa[e] = (e == 0 ? *xptr(cur, cur.hist) : cur.st[e - 1]) - cur.tail;
         }
@@ -898,6 +954,7 @@ fir_mfma_kernel(GroupView g, BlockIO io, int steady_lo, int steady_hi, long long
         /* The previous item's results leave only now: issued before the prefetch they would sit
          * between it and the wait above, and the compiler, joining the loop entry (no stores) with
          * the back edge, would wait for them too. */
+        if (__builtin_amdgcn_ballot_w64(key.odd()) && lane == 0) nf_mark(g, gi, steady_lo + seg);
         if (pending) mfma_store<kAligned16>(acc, pending, pending_skip);
         lds_barrier();
 
@@ -1231,6 +1288,9 @@ bool fir_uses_state_swap(const GroupView &g, const BlockIO &io)
     return !(g.kmax <= max_taps && g.count >= kFirSeqMinChannels && io.n <= kFirSeqMaxBlock);
 }
 
+static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out,
+                                      long long ramp_first, hipStream_t s);
+
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
     if (!fir_uses_state_swap(g, io)) return launch_fir_seq(g, io, s);      /* updates g.state in place */
@@ -1318,6 +1378,7 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
                                    (size_t)0, (size_t)0);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = launch_fir_nf_fixup(g, io, 2048, 2048, (long long)nhead * S, s)) != hipSuccess) return e;
     } else {
         if (nhead > 0) {
             hipLaunchKernelGGL(fir_main_kernel<true>, dim3(nhead, g.count), dim3(kWave), lds_bytes, s, g,
@@ -1342,6 +1403,63 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
     hipLaunchKernelGGL(fir_epilogue_kernel, dim3(g.count), dim3(kEpiThreads), epi_lds, s, g, io);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return launch_fir_commit(g, s);
+}
+
+/* Items of the matrix-core kernels that staged an Inf / NaN (nf_mark), done again the reference's way: every output
+ * from the carried state or s[K-1], taps added oldest first, every product and sum rounded on its own -- so a
+ * non-finite sample shows in exactly the outputs it reaches through the taps, as in RTFIRFilter_update
+ * (ref: src/RTFilter.c:235-247), and those items carry the reference's bits.  One launch per call on such a group;
+ * without a mark every workgroup reads one word and leaves.  Addressing covers rows (seg_* = 2048, ld = the pitch)
+ * and the tiled block layout (ld = 2048, seg_* = doubles between a channel's consecutive tiles) alike.
+ * `ramp_first`: as for the edge kernel -- inside a partial_init ramp the matrix-core kernels own the outputs from
+ * there on. */
+__global__ void __launch_bounds__(256)
+fir_nf_fixup_kernel(GroupView g, BlockIO io, size_t seg_in, size_t seg_out, long long ramp_first)
+{
+    if (*as_const(nf_any(g)) == 0) return;
+    const int tid = threadIdx.x;
+    const long long n = (long long)io.n;
+    const int nitems = (int)((n + kMfmaSeg - 1) / kMfmaSeg);
+    for (int gi = blockIdx.x; gi < g.count; gi += gridDim.x) {
+        const unsigned long long dirty = nf_dirty(g)[gi];
+        if (!dirty) continue;
+        const int chan = g.chan ? g.chan[gi] : g.chan0 + gi;
+        const int dsn = g.design[gi];
+        const int K = g.nb[dsn];
+        const double *b = g.coefs + g.coef_off[dsn];
+        const double *st = g.state + (size_t)gi * g.state_ld;
+        const double tail = st[K - 1];
+        const int t0 = g.aux[2 * gi];
+        const bool ramp = g.kind[dsn] == RTFB_KIND_FIR_PARTIAL && g.aux[2 * gi + 1] < K;
+        const long long first = ramp ? ramp_first : (long long)t0;
+        const double *x = io.in + (size_t)chan * io.ld_in;
+        double *y = io.out + (size_t)chan * io.ld_out;
+        auto at = [](long long m, size_t seg) { return (size_t)(m >> 11) * seg + (size_t)(m & 2047); };
+        for (int item = 0; item < nitems; ++item) {
+            if (!((dirty >> (item & 63)) & 1ull)) continue;
+            const long long m_end = min((long long)(item + 1) * kMfmaSeg, n);
+            for (long long m = (long long)item * kMfmaSeg + tid; m < m_end; m += blockDim.x) {
+                if (m < first) {
+                    /* sample 0 went to stable_init: its output is the sample (the prologue wrote it, the folded
+                     * head of the persistent kernel wrote it again, with the zero taps' products added) */
+                    if (!ramp) y[at(m, seg_out)] = x[at(m, seg_in)];
+                    continue;
+                }
+                const long long mp = m - t0;
+                double acc = mp <= K - 2 ? st[mp] : tail;
+                for (int k = (int)min(mp, (long long)K - 1); k >= 1; --k) acc = acc + b[k] * x[at(m - k, seg_in)];
+                y[at(m, seg_out)] = x[at(m, seg_in)] * b[0] + acc;
+            }
+        }
+    }
+}
+
+static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out,
+                                      long long ramp_first, hipStream_t s)
+{
+    const int grid = g.count < 2048 ? g.count : 2048;
+    hipLaunchKernelGGL(fir_nf_fixup_kernel, dim3(grid), dim3(256), 0, s, g, io, seg_in, seg_out, ramp_first);
+    return hipGetLastError();
 }
 
 /* The tiled block layout [n / 2048][nch][2048] for a group the matrix-core kernel serves with every head folded
@@ -1372,6 +1490,7 @@ hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in
     hipLaunchKernelGGL((fir_mfma_kernel<true, true>), dim3((unsigned)grid), dim3(kMfmaWaves * kWave), mfma_lds, s, g, io,
                        0, (int)(io.n / kMfmaSeg), 0LL, 0LL, 1, seg_in, seg_out);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_fir_nf_fixup(g, io, seg_in, seg_out, 0, s)) != hipSuccess) return e;
     BlockIO last = io;                                          /* the block's last tile as a block of its own */
     last.in = io.in + (io.n / 2048 - 1) * seg_in;
     last.out = io.out + (io.n / 2048 - 1) * seg_out;

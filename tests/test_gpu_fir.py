@@ -330,3 +330,51 @@ def test_end_state_kernels_at_their_boundary(G, taps):
                 if mode == gbank.MODE_SEQUENTIAL:                       # filtered_value is the last output
                     assert util.bits_equal(fv, ob.fval), (taps, partial, n)
             gb.close()
+
+
+@pytest.mark.parametrize("key,nch", [("fir32_lp_0.25", 5), ("fir512_lp_0.25", 3), ("fir7_lp_0.4", 4)])
+def test_mfma_path_confines_inf_and_nan_to_the_outputs_the_reference_reaches(G, key, nch):
+    """RTFIRFilter_update multiplies a sample only by the taps it meets (ref: src/RTFilter.c:235-247): an Inf / NaN
+    at position p reaches outputs p .. p + K - 1 and nothing else.  The Toeplitz tiles of the matrix-core kernel
+    also multiply zero padding with samples up to 15 places either side; those products must not show.  AUTO mode
+    against the oracle: the same outputs non-finite, of the same class (NaN / +Inf / -Inf), every other output
+    within the bar; the carried delay line bit-exact.  Samples placed at tile and item boundaries, in the block's
+    first and last samples, in the halo of the next block, and packed densely in one channel."""
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    _, b, _ = util.design_coefs(key)
+    K = len(b)
+    blocks = [8192 + 4096, 4096 + 300, 8192]
+    n_all = sum(blocks)
+    x = G.make_inputs(4242, nch, n_all)
+    inf, nan = np.inf, np.nan
+    x[0, 0] = inf                                    # the sample stable_init consumes
+    x[0, 4095] = -inf                                # last sample of an item
+    x[0, 4096] = nan                                 # first of the next
+    x[0, 5000] = inf
+    x[0, 5003] = -inf                                # opposite signs inside one window
+    x[1, blocks[0] - 1] = inf                        # last sample of a block: reaches the next block through the state
+    x[1, blocks[0] + 7] = nan
+    x[1, n_all - 1] = -inf
+    x[2, 9000:9000 + 3 * K:3] = inf                  # dense
+    x[2, 256 * 7 + 15] = nan                         # tile edges
+    x[2, 256 * 7 + 16] = inf
+    if nch > 3:
+        x[3, 1] = nan                                # first regular sample of the stream
+    d = G.golden_design(key)
+    gb = gbank.FilterBank([d], [0] * nch, mode=gbank.MODE_AUTO)
+    ob = orc.Bank([G.to_orc_design(d)], [0] * nch)
+    pos = 0
+    for n in blocks:
+        xb = x[:, pos:pos + n]
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = ob.updaten(np.ascontiguousarray(xb), threads=4)
+        got = gb(G.to_dev(xb)).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (key, pos)
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)), (key, pos)
+        assert np.array_equal(np.isneginf(got), np.isneginf(want)), (key, pos)
+        fin = np.isfinite(want)
+        assert np.max(np.abs(got[fin] - want[fin])) <= TOL_MFMA * max(1.0, np.max(np.abs(want[fin]))), (key, pos)
+        st = gb.get_state()[0][:, :ob.state.shape[1]]
+        assert np.array_equal(np.isnan(st), np.isnan(ob.state)) and np.array_equal(st[np.isfinite(st)].tobytes(), ob.state[np.isfinite(ob.state)].tobytes()), (key, pos)
+        pos += n
