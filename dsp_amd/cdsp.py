@@ -229,6 +229,14 @@ _proto("RTFilterStream_set_interleave", c_int, [c_void_p, c_int])
 _proto("RTFilterStream_interleaved", c_int, [c_void_p])
 _proto("RTFilterStream_zero_state", c_int, [c_void_p, c_void_p])
 _proto("RTFilterStream_compose_state", c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p])
+RTFilterStream_allgather_fn = CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
+_proto("RTFilterStream_split_updaten", c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_int, c_int,
+                                               RTFilterStream_allgather_fn, c_void_p, c_void_p])
+_proto("RTFilterStream_split_end_state", c_int, [c_void_p, c_int, c_int, RTFilterStream_allgather_fn, c_void_p, c_void_p])
+_proto("RTFilterStream_split_updaten_rccl", c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_int, c_int,
+                                                    c_void_p, c_void_p])
+_proto("RTFilterStream_split_end_state_rccl", c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p])
+_proto("dsp_debug_rccl_allgather", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p])
 _proto("RTFilterStream_get_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
 _proto("RTFilterStream_set_state", c_int, [c_void_p, _dp, _dp, POINTER(c_int32), c_void_p])
 

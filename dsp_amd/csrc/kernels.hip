@@ -291,7 +291,7 @@ __device__ __forceinline__ void scan_segment(char *smem, int lane, int seg_len, 
     /* ---- prefix combine across lanes: v_j <- end state after lane j ---- */
 #pragma unroll
     for (int lvl = 0; lvl < kScanLevels; ++lvl) {
-        /* levels whose matrix A^(T 2^lvl) has decayed below 2^-75 add nothing (decided per design on
+        /* levels whose matrix A^(T 2^lvl) has decayed below 2^-66 add nothing (decided per design on
          * the host); ragged / seeded segments keep all of them */
         if (!kGeneral && lvl >= nlev) break;
         const int d = 1 << lvl;

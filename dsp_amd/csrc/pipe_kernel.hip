@@ -15,7 +15,7 @@
  *       park prefetched x(i) in LDS, keep two further segments' loads in flight,
  *       zero-state row vectors  v_j = sum_n G[n] x[n]          (table G = A^(31-n) B)
  *       Kogge-Stone prefix over the 64 rows with ZERO carry-in (levels that have
- *       decayed below 2^-75 skipped), publish P_j = state row j would start from
+ *       decayed below 2^-66 skipped), publish P_j = state row j would start from
  *       if the segment started from zero
  *   BACK wave, segment i-1     the critical path
  *       s_j = P_j + A^(32 j) carry    one N x N mat-vec per lane, the lane's own matrix

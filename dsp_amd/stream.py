@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from .bank import DSPError, _check, _stream_ptr
-from .cdsp import RTFB_EUNSUPPORTED, RTFilterDesign_, dspdll
+from .cdsp import RTFB_EUNSUPPORTED, RTFilterDesign_, RTFilterStream_allgather_fn, dspdll
 
 
 class FilterStream:
@@ -48,6 +48,25 @@ class FilterStream:
             self.close()
         except Exception:
             pass
+
+    # ---- the time split across ranks, run by the library (RTFilterStream_split_updaten) ----
+    def split_updaten(self, x_local, out_local, lens, rank, allgather, stream=None):
+        """One call of the C entry: `lens` = chunk lengths of all ranks, `allgather(send_ptr, recv_ptr, count,
+        stream_ptr) -> int` the caller's collective on device pointers (see include/RTFilterStream.h)."""
+        import torch
+        if out_local is None:
+            out_local = torch.empty_like(x_local)
+        arr = (C.c_size_t * len(lens))(*lens)
+        cb = RTFilterStream_allgather_fn(lambda ctx, send, recv, count, sp: int(allgather(send, recv, count, sp)))
+        _check(dspdll.RTFilterStream_split_updaten(self._h, C.c_void_p(out_local.data_ptr()), C.c_void_p(x_local.data_ptr()),
+                                                   arr, rank, len(lens), cb, None, _stream_ptr(stream, self.device)),
+               "RTFilterStream_split_updaten")
+        return out_local
+
+    def split_end_state(self, rank, world, allgather, stream=None):
+        cb = RTFilterStream_allgather_fn(lambda ctx, send, recv, count, sp: int(allgather(send, recv, count, sp)))
+        _check(dspdll.RTFilterStream_split_end_state(self._h, rank, world, cb, None, _stream_ptr(stream, self.device)),
+               "RTFilterStream_split_end_state")
 
     # ---- the path ----
     def updaten_ptr(self, out_ptr, in_ptr, n, stream=None):

@@ -96,6 +96,36 @@ EXPORT int RTFilterStream_zero_state(RTFilterStream *stream, void *hip_stream);
 EXPORT int RTFilterStream_compose_state(RTFilterStream *stream, const double *packs_dev, size_t stride,
                                         size_t count, size_t chunk_len, void *hip_stream);
 
+/* ---- the time split across GPUs as ONE call (no counterpart in the reference) ---------------------------------
+ * The reference call served is RTFilter_updaten on one filter (include/RTFilter.h:89) over a stream whose
+ * consecutive chunks live on consecutive ranks: rank r holds lens[r] samples, the chunks in rank order are the
+ * stream.  _split_updaten runs the protocol above on the caller's stream with the caller's collective -- a C
+ * program needs no Python for it: every rank calls it with the same lens / world and its own rank, in / out = its
+ * chunk (in == out allowed).  The hand-off mode follows from the design and the partition alone (no negotiation):
+ *   decay tail      the design decays (decay_length > 0) and every rank but the last holds >= decay_length samples:
+ *                   ONE all-gather of 2 x pack_len doubles per rank, all ranks filter concurrently;
+ *   composed maps   otherwise, when _exact_split and the ranks 1 .. world-2 hold equal lengths: one all-gather between
+ *                   two passes on ranks >= 1;
+ *   else            RTFB_EUNSUPPORTED: chain the ranks with _export_state / _import_state.
+ * The stream's end state is left on the LAST rank and rides back to rank 0 inside the next call's all-gather, so
+ * consecutive calls continue one stream; _split_end_state puts it on every rank (before a different partition, or
+ * before _sync_to_host / single-GPU calls).
+ * allgather(ctx, send_dev, recv_dev, count, hip_stream): gather `count` doubles from every rank's send_dev into
+ * recv_dev (rank-major, world x count doubles, device memory owned by the stream), ordered on hip_stream (or
+ * complete on return); 0 = success.  Buffers are allocated on the first call per world size; later calls enqueue only.
+ * _rccl: the same with ncclAllGather on an ncclComm_t (RCCL is looked up at run time, libdsp.so does not link it). */
+typedef int (*RTFilterStream_allgather_fn)(void *ctx, const double *send_dev, double *recv_dev, size_t count,
+                                           void *hip_stream);
+EXPORT int RTFilterStream_split_updaten(RTFilterStream *stream, double *out, const double *in, const size_t *lens,
+                                        int rank, int world, RTFilterStream_allgather_fn allgather, void *ctx,
+                                        void *hip_stream);
+EXPORT int RTFilterStream_split_end_state(RTFilterStream *stream, int rank, int world,
+                                          RTFilterStream_allgather_fn allgather, void *ctx, void *hip_stream);
+EXPORT int RTFilterStream_split_updaten_rccl(RTFilterStream *stream, double *out, const double *in, const size_t *lens,
+                                             int rank, int world, void *nccl_comm, void *hip_stream);
+EXPORT int RTFilterStream_split_end_state_rccl(RTFilterStream *stream, int rank, int world, void *nccl_comm,
+                                               void *hip_stream);
+
 /* ---- interleaved segments (orders 9..16 whose decay length is at most 2048 samples; OFF by default) ----------
  * An alternative to the contiguous time split for such designs: RTFilterStream_updaten deals the stream's
  * 2048-sample segments round-robin over `workgroups` workgroups of the two-wave kernel of pipe16_kernel.hip, so

@@ -263,6 +263,83 @@ def test_ranks_on_one_gpu_split_the_stream(G, design, world):
     assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
 
 
+def _c_rank_worker(rank, world, port, n, q, design):
+    """The same rehearsal through the C entry RTFilterStream_split_updaten: the collective is a callback on device
+    pointers (here: hipMemcpy to the host + a gloo all_gather), everything else is the library's."""
+    import ctypes as C
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from dsp_amd import bank as gbank
+    from dsp_amd import stream as gstream
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+        def allgather(send, recv, count, stream_ptr):
+            assert hip.hipStreamSynchronize(stream_ptr) == 0
+            mine = torch.empty(count, dtype=torch.float64)
+            assert hip.hipMemcpy(mine.data_ptr(), send, count * 8, 2) == 0          # device -> host
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            every = torch.cat(parts)
+            assert hip.hipMemcpy(recv, every.data_ptr(), world * count * 8, 1) == 0  # host -> device
+            return 0
+
+        b, a = _bw8() if design == "bw8" else _resonator()
+        fs = gstream.FilterStream(gbank.iir_design(b, a), device=0)
+        lens = [hi - lo for lo, hi in (gstream.time_range(n, world, r) for r in range(world))]
+        outs = []
+        for blk in range(2):
+            lo, hi = gstream.time_range(n, world, rank)
+            x = torch.from_numpy(util.synth(21, 0, blk * n + lo, hi - lo)).cuda()
+            y = fs.split_updaten(x, x if blk else None, lens, rank, allgather)      # the second block in place
+            torch.cuda.synchronize()
+            parts = [None] * world
+            dist.all_gather_object(parts, y.cpu().numpy())
+            outs.append(np.concatenate(parts))
+        fs.split_end_state(rank, world, allgather)
+        st = fs.get_state()[0]
+        if rank == 0:
+            q.put((np.concatenate(outs), st))
+        fs.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("design,world", [("bw8", 2), ("resonator", 3)], ids=["tail-handoff", "composed-maps"])
+def test_ranks_on_one_gpu_split_the_stream_through_the_c_entry(G, design, world):
+    """RTFilterStream_split_updaten / _split_end_state (the multi-GPU leg as a C caller drives it): two blocks of a
+    stream, each cut over the ranks, the second in place; equals one long run of the reference, end state too."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    n = (1 << 20) + 4096
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c_rank_worker, args=(r, world, port, n, q, design)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, st = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, a = _bw8() if design == "bw8" else _resonator()
+    ref = orc.iir(b, a)
+    want = ref.updaten(util.synth(21, 0, 0, 2 * n))
+    assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+    assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+
+
 def test_host_buffers_through_the_gpu(G):
     """RTFilterStream_updaten_host: pageable host arrays, several chunks, state carried across calls, in place."""
     import time
