@@ -289,4 +289,22 @@ def test_config4_benchmarked_wave_shape_both_kinds(G):
             assert util.bits_equal(ys["exact"][0][c].cpu().numpy(), want), (key, c)
             got = ys["auto"][0][c].cpu().numpy()
             assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), (key, c)
+        # The layout the bench times since round 3: the wave's block as [32 tiles][65 536 channels][2048]
+        # (RTFilterBank_updaten_tiled: 64 launches of one resident round each on the schedule for the IIR wave, the
+        # tile-walking matrix-core kernel for the FIR wave).  Same kernel arithmetic as AUTO on rows: equal bits on
+        # every channel and sample, and an equal carried state.
+        want_rows, want_state = ys["auto"]
         del ys
+        xt = torch.empty((B // gbank.TILE, C_, gbank.TILE), dtype=torch.float64, device="cuda")
+        gbank.tile_rows(x, tiles=xt)
+        yt = torch.empty_like(xt)
+        bank = gbank.FilterBank([d], [0] * C_, mode=gbank.MODE_AUTO)
+        bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), B)
+        torch.cuda.synchronize()
+        del xt
+        for t in range(B // gbank.TILE):
+            assert torch.equal(yt[t], want_rows[:, t * gbank.TILE:(t + 1) * gbank.TILE]), (key, t)
+        for p, q in zip(bank.get_state(), want_state):
+            assert util.bits_equal(p, q), key
+        bank.close()
+        del yt, want_rows
