@@ -372,8 +372,18 @@ def main():
     # untimed extra, rank 0: the other ways the same blocks can be handed over (same bank design, fresh banks)
     others = {}
     if rank == 0 and not args.jitter and not args.no_others:
-        def leg(layout_tiled, chained):
-            bk = gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
+        def jitter_bank():
+            # SURVEY.md 8(d)'s variant: every channel its own butterworth(4, wl, wu), band edges jittered inside
+            # [0.25, 0.65] -- no coefficient table is shared (the --jitter run of this script, compact)
+            from dsp_amd import dsp
+            rng = np.random.default_rng(SEED + rank)
+            wl = 0.25 + 0.1 * rng.random(CHANNELS)
+            wu = wl + 0.25 + 0.05 * rng.random(CHANNELS)
+            jb, ja, _ = dsp.design_batch("butterworth", 4, wl, wu)
+            return gbank.FilterBank.from_arrays(gbank.KIND_IIR, jb[:, :9], ja[:, :9], device=local, mode=mode)
+
+        def leg(layout_tiled, chained, jitter=False):
+            bk = jitter_bank() if jitter else gbank.FilterBank([gbank.iir_design(b, a)], [0] * CHANNELS, device=local, mode=mode)
             if layout_tiled == tiled:
                 xs, ys, p = xptr, yptr, pitch
             else:                             # four block buffers in the other layout (re-used by the 16 blocks)
@@ -407,6 +417,8 @@ def main():
                              ("tiles, RTFilterBank_updaten_chained", True, True)):
             if (lt, ch) != (tiled, args.chained):
                 others[name] = leg(lt, ch)
+        others["1024 distinct designs (--jitter), %s, stream order" % ("tiles" if tiled else "dense rows")] = \
+            leg(tiled, False, jitter=True)
 
     if rank == 0:
         samples_per_step = CHANNELS * BLOCK
