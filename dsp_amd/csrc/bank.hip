@@ -2039,8 +2039,8 @@ static int fir_updaten_tiled(RTFilterBank *bank, double *out, const double *in, 
                        "<= 1024 designs, scan-safe or RTFB_MODE_SCAN) and by the matrix-core FIR kernel (one launch "
                        "group of stable_init designs with 2..2047 taps, n a multiple of 4096, not "
                        "RTFB_MODE_SEQUENTIAL)";
-    if (bank->groups.size() != 1 || bank->groups[0].cls != kFir || bank->mode == RTFB_MODE_SEQUENTIAL)
-        return fail(RTFB_EUNSUPPORTED, what);
+    if (bank->groups.size() != 1 || bank->groups[0].cls != kFir) return fail(RTFB_EUNSUPPORTED, what);
+    const bool exact = bank->mode == RTFB_MODE_SEQUENTIAL;
     Group &g = bank->groups[0];
     DeviceScope ds(bank->device);
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
@@ -2049,7 +2049,7 @@ static int fir_updaten_tiled(RTFilterBank *bank, double *out, const double *in, 
         return fail(RTFB_EINVAL, "in / out must be 16-byte aligned");
     GroupView v = view_of(bank, g);
     v.fir_mfma = g.kmax >= kFirMfmaMinTaps ? 1 : 0;
-    if (!fir_tiled_supported(v, n)) return fail(n % 4096 ? RTFB_ESIZE : RTFB_EUNSUPPORTED, what);
+    if (!fir_tiled_supported(v, n, exact)) return fail(n % 4096 ? RTFB_ESIZE : RTFB_EUNSUPPORTED, what);
     int rc = chain_close(bank, s);
     if (rc) return rc;
     BlockIO io;
@@ -2076,7 +2076,7 @@ static int fir_updaten_tiled(RTFilterBank *bank, double *out, const double *in, 
         io.in = g.d_scratch;
     } else if (in < out + total && out < in + total)
         return fail(RTFB_EINVAL, "RTFilterBank_updaten_tiled: in and out overlap without being equal");
-    HIP_TRY(launch_fir_tiled(v, io, seg, seg, s));
+    HIP_TRY(launch_fir_tiled(v, io, seg, seg, exact, g.pace_ns, s));
     return RTFB_OK;
 }
 

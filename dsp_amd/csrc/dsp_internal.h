@@ -153,8 +153,9 @@ hipError_t launch_iir_pipe_sos(int sections, const GroupView &g, const BlockIO &
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s);
 /* the matrix-core FIR kernel on the tiled block layout [n / 2048][nch][2048] (io.ld_* = 2048; seg_* = doubles
  * between consecutive tiles of a channel) */
-bool fir_tiled_supported(const GroupView &g, size_t n);
-hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, hipStream_t s);
+bool fir_tiled_supported(const GroupView &g, size_t n, bool exact);
+hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
+                            double pace_ns, hipStream_t s);
 /* false when launch_fir takes the lane-per-channel kernel, which updates g.state in place (no ping-pong swap) */
 bool fir_uses_state_swap(const GroupView &g, const BlockIO &io);
 hipError_t launch_reset(const GroupView &g, hipStream_t s);

@@ -22,6 +22,8 @@
  *             written to the other half of a ping-pong pair; filtered_value,
  *             initialized
  */
+#include <type_traits>
+
 #include "dsp_internal.h"
 #include "kernel_common.h"
 
@@ -1290,6 +1292,8 @@ bool fir_uses_state_swap(const GroupView &g, const BlockIO &io)
 
 static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out,
                                       long long ramp_first, hipStream_t s);
+static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
+                                  double pace_ns, bool tiled, hipStream_t s);
 
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
@@ -1299,6 +1303,21 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
     hipLaunchKernelGGL(fir_prologue_kernel, dim3(pro_blocks), dim3(256), 0, s, g, io);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+
+    /* Short filters on whole aligned tiles of a bank wide enough to fill the GPU with one workgroup per channel: the
+     * streaming kernel (rows are tiles a pitch apart) -- in the bit-exact mode always (65 536 x 64K, 32 taps: 3.68 ->
+     * 4.33 TB/s, 16 taps 4.46 -> 4.79, 7 taps 5.03 -> 5.24), otherwise up to 8 taps (5.17 -> 5.24, and the
+     * reference's bits); from 9 taps on the matrix-core kernel leads on rows (4.99 against 4.69-4.80).
+     * profiles/r3_fir_tile.txt */
+    if (!g.has_partial && g.kmax >= 2 && g.kmax <= 32 && (!g.fir_mfma || g.kmax <= 8) && g.count >= 512 &&
+        io.aligned16 && io.n % kMfmaSeg == 0 && io.n <= ((size_t)1 << 30)) {
+        if ((e = launch_fir_tile(g, io, 2048, 2048, !g.fir_mfma, 0.0, false, s)) != hipSuccess) return e;
+        const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
+        const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
+        hipLaunchKernelGGL(fir_epilogue_taps_kernel, dim3(passes, g.count), dim3(kWave), lds_taps, s, g, io);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return launch_fir_commit(g, s);
+    }
 
     const int total = S + g.kmax - 1;
     const size_t lds_bytes = (size_t)(total + (total >> 5) + 1) * sizeof(double);
@@ -1462,22 +1481,251 @@ static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, siz
     return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------------ */
+/* Short FIR (2 <= K <= 32 taps, stable_init designs) on the tiled block layout: */
+/* the streaming kernel.  One workgroup of 256 threads per channel walks the      */
+/* channel's tiles in time order -- the access pattern of the pipelined IIR       */
+/* kernel and of its copy twin, which is what the tiled layout and the schedule   */
+/* are made for: two tiles of loads in flight per workgroup, four     */
+/* workgroups per CU, every launch one resident round of channels.  A thread      */
+/* computes 8 consecutive outputs of a tile from LDS (tile + the 32 samples in    */
+/* front of it, 10 doubles per 8 samples: the 64-byte windows of the lanes are    */
+/* conflict-free), taps oldest first, two 8-sample blocks of the window in        */
+/* registers at a time; the taps are wave-uniform scalars and only the K the      */
+/* design has are ever multiplied: no padding products, so an Inf / NaN reaches   */
+/* exactly the outputs it reaches in RTFIRFilter_update (ref: src/RTFilter.c:     */
+/* 235-247).  kExact: every product and sum rounded on its own, the reference's   */
+/* bits; else fused multiply-adds (the matrix-core path's accuracy class).        */
+/* The outputs leave through LDS as well: stored straight from the registers,     */
+/* 64 contiguous bytes per lane, every store instruction touches 64 lines a        */
+/* quarter each and a 65 536-channel wave takes 16.1 ms; stored as 16 contiguous   */
+/* bytes per lane (one more barrier per tile) 12.x ms.                             */
+namespace {
+constexpr int kTfThreads = 256;
+constexpr int kTfHalo = 32;                                    /* samples in front of a tile (>= K-1) */
+constexpr int kTfLdsDoubles = (2048 + kTfHalo) / 8 * 10;      /* the tile and the samples in front of it */
+constexpr int kTfLdsOut = 2048;                                /* behind them: the tile's outputs on their way out */
+}  // namespace
+
+template <int KP, bool kExact>
+__global__ void __launch_bounds__(kTfThreads, 4)
+fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out, unsigned int pace_fx)
+{
+    static_assert(KP == 8 || KP == 16 || KP == 32, "window blocks of 8 samples");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *xs = reinterpret_cast<double *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int gi = gi0 + (int)blockIdx.x;
+    const int chan = g.chan ? as_const(g.chan)[gi] : g.chan0 + gi;
+    const int dsn = as_const(g.design)[gi];
+    const int K = as_const(g.nb)[dsn];
+    cdouble_p cb = as_const(g.coefs + as_const(g.coef_off)[dsn]);
+    const double *st = g.state + (size_t)gi * g.state_ld;
+    const double tail = as_const(st)[K - 1];
+    const int t0 = as_const(g.aux)[2 * gi];                     /* 1: the prologue gave sample 0 to stable_init */
+    const int nseg = (int)(io.n / 2048);
+    const double *src = io.in + (size_t)chan * io.ld_in;        /* tiled layout: ld = 2048, seg_* = nch x 2048; rows: */
+    double *dst = io.out + (size_t)chan * io.ld_out;            /* ld = the pitch, seg_* = 2048                      */
+    double bk[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) bk[k] = cb[k < K ? k : K - 1];
+
+    /* Every thread issues the same five loads per tile and the same four stores, whatever the tile: past the end
+     * of the block the loads go to the channel's first tile, and all threads fetch a piece of the 32 samples in
+     * front of the tile (16 of them keep it).  With nothing conditional the compiler counts vmcnt exactly -- two
+     * tiles of loads really stay in flight; with guarded loads it drained the queue at every tile (15.8 ms per
+     * 65 536-channel wave instead of 12.x). */
+    d2 buf0[4], buf1[4], h0, h1;
+    auto load = [&](int s, d2(&buf)[4], d2 &h) {
+        const int sc = s < nseg ? s : 0;
+        const double *p = src + (size_t)sc * seg_in + 2 * tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[i] = stream_load(reinterpret_cast<const d2 *>(p + 512 * i));
+        h = *reinterpret_cast<const d2 *>(src + (size_t)(sc > 0 ? sc - 1 : 0) * seg_in + (2048 - kTfHalo) + 2 * (tid & 15));
+    };
+    /* sample i of the tile (i >= -32) sits at LDS double (i + 32) + 2 ((i + 32) >> 3) */
+    auto stage = [&](const d2(&buf)[4], const d2 &h, bool first) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 2 * (i * kTfThreads + tid) + kTfHalo;
+            *reinterpret_cast<d2 *>(xs + e + 2 * (e >> 3)) = buf[i];
+        }
+        if (tid < kTfHalo / 2) {
+            const int e = 2 * tid;
+            d2 v = h;
+            if (first) v = (d2){0.0, 0.0};
+            *reinterpret_cast<d2 *>(xs + e + 2 * (e >> 3)) = v;
+        }
+    };
+    const int o = 8 * tid;                                      /* this thread's outputs of a tile: o .. o + 7 */
+    auto block = [&](int q, double(&w)[8]) {                    /* samples o + 8 q .. o + 8 q + 7 */
+        const d2 *p = reinterpret_cast<const d2 *>(xs + 10 * (tid + q + kTfHalo / 8));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const d2 v = p[m];
+            w[2 * m] = v.x;
+            w[2 * m + 1] = v.y;
+        }
+    };
+    /* kGuard: the block's first tile -- outputs that still sit on the carried state, samples that do not exist
+     * (before the first regular sample t0) contribute NOTHING (not even a zero product) */
+    auto compute = [&](int s, auto guard_tag) {
+        constexpr bool kGuard = decltype(guard_tag)::value;
+        constexpr int NB = KP / 8;
+        double acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = tail;
+            if constexpr (kGuard) {
+                const int mp = o + j - t0;
+                if (mp >= 0 && mp <= K - 2) acc[j] = st[mp];
+            }
+        }
+        double lo[8], hi[8];
+        block(-NB, lo);
+#pragma unroll
+        for (int q = -NB; q < 0; ++q) {
+            block(q + 1, hi);
+#pragma unroll
+            for (int kk = -8 * q; kk >= -8 * q - 7; --kk) {
+                if (kk > KP - 1) continue;
+                if (kk < K) {                                   /* wave-uniform */
+                    const double t = bk[kk];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int idx = j - kk - 8 * q;         /* 0 .. 14 within (lo, hi) */
+                        const double x = idx < 8 ? lo[idx < 8 ? idx : 0] : hi[idx >= 8 ? idx - 8 : 0];
+                        double r;
+                        if constexpr (kExact) {
+                            const double pr = t * x;
+                            r = acc[j] + pr;
+                        } else
+                            r = __builtin_fma(t, x, acc[j]);
+                        if constexpr (kGuard) acc[j] = (o + j - kk >= t0) ? r : acc[j];
+                        else acc[j] = r;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = hi[j];
+        }
+        double y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (kExact) {
+                const double pr = lo[j] * bk[0];
+                y[j] = pr + acc[j];
+            } else
+                y[j] = __builtin_fma(lo[j], bk[0], acc[j]);
+        }
+        if constexpr (kGuard) {                                 /* sample 0 went to stable_init: its output is the sample */
+            if (tid == 0 && t0 > 0) y[0] = lo[0];
+        }
+        double *ys = xs + kTfLdsDoubles;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) *reinterpret_cast<d2 *>(ys + o + 2 * m) = (d2){y[2 * m], y[2 * m + 1]};
+        lds_barrier();
+        double *out = dst + (size_t)s * seg_out + 2 * tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            stream_store(reinterpret_cast<d2 *>(out + 512 * i), *reinterpret_cast<const d2 *>(ys + 512 * i + 2 * tid));
+    };
+
+    load(0, buf0, h0);
+    load(1, buf1, h1);
+    unsigned long long due_fx = 0;
+    if (pace_fx) due_fx = (__builtin_amdgcn_s_memrealtime() << 10) + pace_fx;
+    auto pace = [&]() {                                         /* see pipe_kernel.hip: the prefetch keeps to a schedule */
+        if (pace_fx) {
+            while ((__builtin_amdgcn_s_memrealtime() << 10) < due_fx) __builtin_amdgcn_s_sleep(1);
+            due_fx += pace_fx;
+        }
+    };
+    /* one tile: park it, request the tile two ahead into the registers just freed, compute.  The block's first tile
+     * (guarded: it loads state words under conditions) stays outside the loop, whose body then holds nothing
+     * conditional. */
+    auto tile = [&](int s, d2(&buf)[4], d2 &h, auto guard_tag) {
+        lds_barrier();                                          /* the tile before has been read */
+        stage(buf, h, decltype(guard_tag)::value);
+        pace();
+        load(s + 2, buf, h);
+        lds_barrier();
+        compute(s, guard_tag);
+    };
+    tile(0, buf0, h0, std::true_type{});
+    tile(1, buf1, h1, std::false_type{});                       /* nseg is even: n is a multiple of 4096 */
+    for (int s = 2; s < nseg; s += 2) {
+        tile(s, buf0, h0, std::false_type{});
+        tile(s + 1, buf1, h1, std::false_type{});
+    }
+}
+
+/* rounds of at most `round` channels, each launch on the schedule when it fills the GPU */
+/* Arithmetic: the reference's (every product and sum rounded on its own) when asked for (RTFB_MODE_SEQUENTIAL) and,
+ * unasked, up to 16 taps, where it costs nothing (65 536 x 64K, tiled: 5.63 TB/s either way; 24 taps 5.28 against
+ * 5.59 fused, 32 taps 4.5 against 5.54: profiles/r3_fir_tile.txt).  Schedule: from 9 taps on (below, the workgroups
+ * stay in step by themselves and run 2-3 % faster without: 5.74-5.81 against 5.65 TB/s). */
+static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
+                                  double pace_ns, bool tiled, hipStream_t s)
+{
+    if (g.kmax <= 16) exact = true;
+    if (pace_ns < 0.0 && (g.kmax <= 8 || !tiled)) pace_ns = 0.0;
+    const int round = 1024;                                     /* 4 workgroups per CU */
+    const size_t lds = (size_t)(kTfLdsDoubles + kTfLdsOut) * sizeof(double);
+    for (int off = 0; off < g.count; off += round) {
+        const int cnt = g.count - off < round ? g.count - off : round;
+        unsigned int pace_fx = 0;
+        if (pace_ns != 0.0 && 4 * cnt >= 3 * round && io.n / 2048 >= 12) {
+            const double ns = pace_ns > 0.0 ? pace_ns : (double)cnt * 32768.0 / 5950.0;
+            pace_fx = (unsigned int)(ns / 10.0 * 1024.0);
+        }
+#define DSP_TF(KP)                                                                                                  \
+    if (exact)                                                                                                      \
+        hipLaunchKernelGGL((fir_tile_kernel<KP, true>), dim3(cnt), dim3(kTfThreads), lds, s, g, io, off, seg_in,    \
+                           seg_out, pace_fx);                                                                       \
+    else                                                                                                            \
+        hipLaunchKernelGGL((fir_tile_kernel<KP, false>), dim3(cnt), dim3(kTfThreads), lds, s, g, io, off, seg_in,   \
+                           seg_out, pace_fx);
+        if (g.kmax <= 8) { DSP_TF(8) }
+        else if (g.kmax <= 16) { DSP_TF(16) }
+        else { DSP_TF(32) }
+#undef DSP_TF
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 /* The tiled block layout [n / 2048][nch][2048] for a group the matrix-core kernel serves with every head folded
  * (no partial_init channels, 2 <= K <= 2047) and n a multiple of the 4096-output item: prologue (sample 0 of a
  * reset stream sits at the same place in both layouts), ONE persistent launch, the end state from the block's last
  * tile (it holds the K-1 samples the state depends on) and the commit.  io.ld_* = 2048. */
-bool fir_tiled_supported(const GroupView &g, size_t n)
+bool fir_tiled_supported(const GroupView &g, size_t n, bool exact)
 {
-    return g.fir_mfma && !g.has_partial && g.kmax >= 2 && g.kmax <= 2047 && n > 0 && n % kMfmaSeg == 0 &&
-           n <= ((size_t)1 << 30);
+    if (g.has_partial || g.kmax < 2 || n == 0 || n % kMfmaSeg || n > ((size_t)1 << 30)) return false;
+    if (g.kmax <= kTfHalo) return true;                         /* the streaming kernel, either arithmetic */
+    return !exact && g.fir_mfma && g.kmax <= 2047;              /* the matrix-core kernel */
 }
 
-hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, hipStream_t s)
+hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
+                            double pace_ns, hipStream_t s)
 {
     const int pro_blocks = (g.count + 255) / 256;
     hipLaunchKernelGGL(fir_prologue_kernel, dim3(pro_blocks), dim3(256), 0, s, g, io);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (g.kmax <= kTfHalo) {
+        if ((e = launch_fir_tile(g, io, seg_in, seg_out, exact, pace_ns, true, s)) != hipSuccess) return e;
+        BlockIO last = io;                                      /* the block's last tile as a block of its own */
+        last.in = io.in + (io.n / 2048 - 1) * seg_in;
+        last.out = io.out + (io.n / 2048 - 1) * seg_out;
+        last.n = 2048;
+        const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
+        const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
+        hipLaunchKernelGGL(fir_epilogue_taps_kernel, dim3(passes, g.count), dim3(kWave), lds_taps, s, g, last);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return launch_fir_commit(g, s);
+    }
     const int hist = 16 * (mfma_steps16(g.kmax) - 1);
     int xtotal = hist + kMfmaSeg + 16;
     if (xtotal < kMfmaPreElems) xtotal = kMfmaPreElems;

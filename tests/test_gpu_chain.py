@@ -180,15 +180,26 @@ def test_tiled_wide_bank_round_by_round_matches_rows_to_the_bit(G, nch, ntiles):
     # is held to the oracle at this shape in test_gpu_iir / test_gpu_fullsize, and the outputs above are its bits
 
 
+@pytest.mark.parametrize("mode", ["auto", "exact"])
 @pytest.mark.parametrize("key,nch", [("fir32_lp_0.25", 40), ("fir7_lp_0.4", 17), ("fir7_lp_0.4", 1), ("fir512_lp_0.25", 6)])
-def test_tiled_fir_matches_rows(G, key, nch):
-    """FIR banks on the tiled layout (matrix-core kernel, every head folded): blocks of 2, 4 and 2 tiles, the first
-    on a fresh stream (stable_init), the last in place.  Same kernel arithmetic as RTFilterBank_updaten in AUTO
-    mode: equal bits, the carried delay line included; and the bit-exact mode / oracle within 1e-12."""
+def test_tiled_fir_matches_rows(G, key, nch, mode):
+    """FIR banks on the tiled layout: blocks of 2, 4 and 2 tiles, the first on a fresh stream (stable_init), the
+    last in place.  Filters of <= 32 taps run on the streaming kernel (fir_tile_kernel): in RTFB_MODE_SEQUENTIAL
+    with the reference's arithmetic -- the BITS of the rows entry in that mode and of the oracle --, in AUTO with
+    fused multiply-adds (within 1e-12).  Longer filters run on the matrix-core kernel in AUTO (the bits of
+    RTFilterBank_updaten in AUTO) and are refused in SEQUENTIAL.  The carried delay line is bit-exact in every case."""
     import torch
     from dsp_amd import bank as gbank
+    exact = mode == "exact"
+    m = gbank.MODE_SEQUENTIAL if exact else gbank.MODE_AUTO
+    K = len(util.design_coefs(key)[1])
     blocks = [2 * gbank.TILE, 4 * gbank.TILE, 2 * gbank.TILE]
-    a_bank, b_bank = _bank(G, key, nch), _bank(G, key, nch)
+    a_bank, b_bank = _bank(G, key, nch, mode=m), _bank(G, key, nch, mode=m)
+    if exact and K > 32:
+        x = torch.zeros((nch, blocks[0]), dtype=torch.float64, device="cuda")
+        with pytest.raises(Exception):
+            b_bank.updaten_tiled_ptr(x.data_ptr(), x.data_ptr(), blocks[0])
+        return
     pos, ys = 0, []
     for i, n in enumerate(blocks):
         x = G.to_dev(G.make_inputs(78, nch, n, pos))
@@ -197,19 +208,30 @@ def test_tiled_fir_matches_rows(G, key, nch):
         yt = xt if i == 2 else torch.empty_like(xt)
         b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
         got = gbank.untile_rows(yt)
-        assert torch.equal(got, want), (key, i)
+        if exact or K > 32:
+            assert torch.equal(got, want), (key, i)
+        else:
+            assert util.rel_to_peak(got.cpu().numpy(), want.cpu().numpy()).max() <= TOL, (key, i)
         ys.append(got.cpu().numpy())
         pos += n
-    for p, q in zip(a_bank.get_state(), b_bank.get_state()):
-        assert util.bits_equal(p, q)
+    sa, sb = a_bank.get_state(), b_bank.get_state()
+    assert util.bits_equal(sa[0], sb[0]) and np.array_equal(sa[2], sb[2])
     want_o, ob = _oracle_rows(G, key, G.make_inputs(78, nch, sum(blocks), 0))
-    assert util.rel_to_peak(np.concatenate(ys, axis=1), want_o).max() <= TOL
+    got_all = np.concatenate(ys, axis=1)
+    if exact:
+        assert util.bits_equal(got_all, want_o)
+    assert util.rel_to_peak(got_all, want_o).max() <= TOL
     assert util.bits_equal(b_bank.get_state()[0][:, :ob.state.shape[1]], ob.state)     # bit-exact end-state kernels
 
 
+def _rel_dev(y, yref):
+    peak = yref.abs().amax(dim=1).clamp_min(1e-300)
+    return ((y - yref).abs().amax(dim=1) / peak).max().item()
+
+
 def test_tiled_fir_wide_bank(G):
-    """More channels than four grids of the persistent kernel: workgroup w walks channels w, w + grid, w + 2 grid ...
-    Against the rows entry (bits) and the oracle on sampled channels."""
+    """More channels than three resident rounds: the streaming kernel goes round by round on the schedule.
+    Against the rows entry and the oracle on sampled channels."""
     import torch
     from dsp_amd import bank as gbank
     from oracle import oracle as orc
@@ -224,10 +246,9 @@ def test_tiled_fir_wide_bank(G):
         yt = torch.empty_like(xt)
         b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
         got = gbank.untile_rows(yt)
-        assert torch.equal(got, want), i
+        assert _rel_dev(got, want) <= TOL, i           # streaming kernel (fused) vs matrix-core kernel
         outs.append(got)
-    for p, q in zip(a_bank.get_state(), b_bank.get_state()):
-        assert util.bits_equal(p, q)
+    assert util.bits_equal(a_bank.get_state()[0], b_bank.get_state()[0])
     d = G.to_orc_design(G.golden_design(key))
     for c in (0, 767, 768, 3399):
         xin = util.synth(0x5EED0004, c, 0, 2 * n)
@@ -244,7 +265,7 @@ def test_tiled_entry_refuses_what_it_does_not_serve(G):
     fir = _bank(G, "fir32_lp_0.25", 4)
     with pytest.raises(Exception):                          # one tile: not a multiple of the 4096-output item
         fir.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), gbank.TILE)
-    seq = _bank(G, "fir32_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)
+    seq = _bank(G, "fir512_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)        # > 32 taps: only the matrix cores serve it
     with pytest.raises(Exception):
         seq.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
     _, b, _ = util.design_coefs("mavg32")

@@ -378,3 +378,40 @@ def test_mfma_path_confines_inf_and_nan_to_the_outputs_the_reference_reaches(G, 
         st = gb.get_state()[0][:, :ob.state.shape[1]]
         assert np.array_equal(np.isnan(st), np.isnan(ob.state)) and np.array_equal(st[np.isfinite(st)].tobytes(), ob.state[np.isfinite(ob.state)].tobytes()), (key, pos)
         pos += n
+
+
+@pytest.mark.parametrize("key,mode", [("fir32_lp_0.25", "exact"), ("fir7_lp_0.4", "exact"), ("fir7_lp_0.4", "auto"),
+                                      ("rand16", "exact"), ("rand2", "auto")])
+def test_streaming_kernel_on_rows_of_a_wide_bank(G, key, mode):
+    """fir_tile_kernel on dense rows (banks of >= 512 channels, whole 4096-sample pieces, <= 32 taps: always in
+    RTFB_MODE_SEQUENTIAL, up to 8 taps in AUTO): the reference's bits against the oracle on every channel, over a
+    fresh stream (stable_init), carried blocks, an in-place block and a ragged block in between (which the other
+    kernels take); unaligned row pitch falls back as well."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    nch = 600
+    if key.startswith("rand"):
+        b = np.random.default_rng(9).normal(size=int(key[4:])) / int(key[4:])
+    else:
+        b = util.design_coefs(key)[1]
+    d = gbank.fir_design(b)
+    gb = gbank.FilterBank([d], [0] * nch, mode=gbank.MODE_SEQUENTIAL if mode == "exact" else gbank.MODE_AUTO)
+    ob = orc.Bank([G.to_orc_design(d)], [0] * nch)
+    pos = 0
+    for i, n in enumerate([8192, 4096, 1000, 12288]):
+        x = G.make_inputs(91, nch, n, pos)
+        want = ob.updaten(x, threads=8)
+        xd = G.to_dev(x)
+        if i == 1:
+            gb.updaten_ptr(xd.data_ptr(), n, xd.data_ptr(), n, n)          # in place
+            got = xd.cpu().numpy()
+        else:
+            got = gb(xd).cpu().numpy()
+        if mode == "exact" or n % 4096 == 0:
+            assert util.bits_equal(got, want), (key, mode, i)
+        else:                                           # AUTO, ragged: the matrix-core kernel
+            assert util.rel_to_peak(got, want).max() <= TOL_MFMA, (key, mode, i)
+        st = gb.get_state()
+        assert util.bits_equal(st[0][:, :ob.state.shape[1]], ob.state) and np.array_equal(st[2], ob.init)
+        pos += n

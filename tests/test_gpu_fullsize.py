@@ -290,9 +290,9 @@ def test_config4_benchmarked_wave_shape_both_kinds(G):
             got = ys["auto"][0][c].cpu().numpy()
             assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), (key, c)
         # The layout the bench times since round 3: the wave's block as [32 tiles][65 536 channels][2048]
-        # (RTFilterBank_updaten_tiled: 64 launches of one resident round each on the schedule for the IIR wave, the
-        # tile-walking matrix-core kernel for the FIR wave).  Same kernel arithmetic as AUTO on rows: equal bits on
-        # every channel and sample, and an equal carried state.
+        # (RTFilterBank_updaten_tiled: 64 launches of one resident round each on the schedule -- the pipelined kernel
+        # for the IIR wave, the streaming FIR kernel for the 32-tap wave).  Against AUTO on rows on every channel and
+        # sample (IIR: the same arithmetic, equal bits; FIR: within the bar), and an equal carried state.
         want_rows, want_state = ys["auto"]
         del ys
         xt = torch.empty((B // gbank.TILE, C_, gbank.TILE), dtype=torch.float64, device="cuda")
@@ -302,9 +302,17 @@ def test_config4_benchmarked_wave_shape_both_kinds(G):
         bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), B)
         torch.cuda.synchronize()
         del xt
+        iir = key.startswith("bw")
         for t in range(B // gbank.TILE):
-            assert torch.equal(yt[t], want_rows[:, t * gbank.TILE:(t + 1) * gbank.TILE]), (key, t)
-        for p, q in zip(bank.get_state(), want_state):
-            assert util.bits_equal(p, q), key
+            ref = want_rows[:, t * gbank.TILE:(t + 1) * gbank.TILE]
+            if iir:                                        # the same kernel arithmetic: equal bits
+                assert torch.equal(yt[t], ref), (key, t)
+            else:                                          # 32 taps: the streaming kernel (fused) against the matrix cores
+                assert (yt[t] - ref).abs().max().item() <= TOL * ref.abs().max().item(), (key, t)
+        got_state = bank.get_state()
+        assert util.bits_equal(got_state[0], want_state[0]), key        # carried state / delay line: bit-exact either way
+        assert np.array_equal(got_state[2], want_state[2]), key
+        if iir:
+            assert util.bits_equal(got_state[1], want_state[1]), key
         bank.close()
         del yt, want_rows

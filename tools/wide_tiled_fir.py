@@ -15,7 +15,10 @@ key = sys.argv[3] if len(sys.argv) > 3 else "fir32_lp_0.25"
 pitch = n + 128
 x = torch.empty(Cn * pitch, dtype=torch.float64, device=dev).uniform_(-1, 1)
 y = torch.empty_like(x)
-_, b, _ = util.design_coefs(key)
+if key.startswith("rand"):
+    b = np.random.default_rng(5).normal(size=int(key[4:])) / int(key[4:])
+else:
+    _, b, _ = util.design_coefs(key)
 
 def timed(call, nsteps=4):
     call(); call()
@@ -30,9 +33,17 @@ def timed(call, nsteps=4):
 def show(what, ms):
     print("%-34s %.3f ms  %.0f Msamples/s  %.2f TB/s" % (what, ms, Cn * n / ms / 1e3, Cn * n * 16 / ms / 1e9), flush=True)
 
-bank = gbank.FilterBank([gbank.fir_design(b)], [0] * Cn, device=0)
-show("dense rows, pitch n+128", timed(lambda: bank.updaten_ptr(y.data_ptr(), pitch, x.data_ptr(), pitch, n, stream)))
-bank.close()
-bank = gbank.FilterBank([gbank.fir_design(b)], [0] * Cn, device=0)
-show("tiled [tile][ch][2048]", timed(lambda: bank.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), n, stream)))
-bank.close()
+for mode, name in ((gbank.MODE_AUTO, "AUTO"), (gbank.MODE_SEQUENTIAL, "SEQUENTIAL (bit-exact)")):
+    bank = gbank.FilterBank([gbank.fir_design(b)], [0] * Cn, device=0, mode=mode)
+    show("dense rows, pitch n+128, %s" % name, timed(lambda: bank.updaten_ptr(y.data_ptr(), pitch, x.data_ptr(), pitch, n, stream)))
+    bank.close()
+for mode, name in ((gbank.MODE_AUTO, "AUTO"), (gbank.MODE_SEQUENTIAL, "SEQUENTIAL (bit-exact)")):
+    for pace in (-1, 0):
+        bank = gbank.FilterBank([gbank.fir_design(b)], [0] * Cn, device=0, mode=mode)
+        bank.set_pace(pace)
+        try:
+            show("tiled, %s, %s" % (name, "paced" if pace else "no schedule"),
+                 timed(lambda: bank.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), n, stream)))
+        except Exception as e:
+            print("tiled, %s: refused (%s)" % (name, str(e)[:60]))
+        bank.close()
