@@ -1670,7 +1670,9 @@ static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t 
 {
     if (g.kmax <= 16) exact = true;
     if (pace_ns < 0.0 && (g.kmax <= 8 || !tiled)) pace_ns = 0.0;
-    const int round = 1024;                                     /* 4 workgroups per CU */
+    /* one resident round (4 workgroups per CU) per launch, so that the workgroups of a launch stay in step; short
+     * blocks (under 12 tiles: mostly pipeline fill, never paced) go as one launch */
+    const int round = io.n / 2048 >= 12 ? 1024 : (g.count > 1024 ? g.count : 1024);
     const size_t lds = (size_t)(kTfLdsDoubles + kTfLdsOut) * sizeof(double);
     for (int off = 0; off < g.count; off += round) {
         const int cnt = g.count - off < round ? g.count - off : round;

@@ -274,3 +274,49 @@ def test_tiled_entry_refuses_what_it_does_not_serve(G):
         ramp.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
     assert np.all(fir.get_state()[2] != 0)                  # nothing was enqueued: every channel is still fresh
     assert torch.all(fir(x) == 0)                           # and the bank still works
+
+
+@pytest.mark.parametrize("key,mode", [("fir32_lp_0.25", "auto"), ("fir32_lp_0.25", "exact"), ("fir7_lp_0.4", "auto")])
+def test_tiled_fir_streaming_kernel_with_inf_and_nan(G, key, mode):
+    """The streaming FIR kernel multiplies a sample by the K taps it meets and nothing else: Inf / NaN at tile
+    boundaries, in the 32 samples in front of a tile, in the first and last samples of a block and packed densely
+    show in exactly the outputs the oracle has them in, with the same class; every other output within the bar
+    (the reference's bits in the exact mode); the carried delay line as the oracle's."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    nch, blocks = 6, [2 * gbank.TILE, 4 * gbank.TILE]
+    K = len(util.design_coefs(key)[1])
+    x = G.make_inputs(4243, nch, sum(blocks))
+    x[0, 0] = np.inf
+    x[0, 2047] = -np.inf
+    x[0, 2048] = np.nan
+    x[1, 4095] = np.inf                                     # last sample of the first block
+    x[1, 4096 + 5] = np.nan
+    x[2, 3000:3000 + 3 * K:3] = np.inf
+    x[2, 3001] = -np.inf
+    x[3, 1] = np.nan
+    x[4, sum(blocks) - 1] = -np.inf
+    d = G.golden_design(key)
+    gb = gbank.FilterBank([d], [0] * nch, mode=gbank.MODE_SEQUENTIAL if mode == "exact" else gbank.MODE_AUTO)
+    ob = orc.Bank([G.to_orc_design(d)], [0] * nch)
+    pos = 0
+    for n in blocks:
+        xb = np.ascontiguousarray(x[:, pos:pos + n])
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = ob.updaten(xb, threads=4)
+        xt = gbank.tile_rows(G.to_dev(xb))
+        yt = torch.empty_like(xt)
+        gb.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        got = gbank.untile_rows(yt).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (key, pos)
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want))
+        fin = np.isfinite(want)
+        if mode == "exact" or K <= 16:
+            assert np.array_equal(got[fin].tobytes(), want[fin].tobytes()), (key, pos)
+        else:
+            assert np.max(np.abs(got[fin] - want[fin])) <= TOL * max(1.0, np.max(np.abs(want[fin]))), (key, pos)
+        st = gb.get_state()[0][:, :ob.state.shape[1]]
+        assert np.array_equal(np.isnan(st), np.isnan(ob.state))
+        assert st[np.isfinite(ob.state)].tobytes() == ob.state[np.isfinite(ob.state)].tobytes()
+        pos += n
