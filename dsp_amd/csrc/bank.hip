@@ -2036,8 +2036,8 @@ static int pipe_block(const RTFilterBank *bank, double *out, size_t ld_out, cons
 static int fir_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream)
 {
     const char *what = "the tiled block layout is served by the pipelined IIR kernel (one launch group of order <= 8, "
-                       "<= 1024 designs, scan-safe or RTFB_MODE_SCAN) and by the matrix-core FIR kernel (one launch "
-                       "group of stable_init designs with 2..2047 taps, n a multiple of 4096, not "
+                       "<= 1024 designs, scan-safe or RTFB_MODE_SCAN) and by the FIR kernels (one launch group, n a "
+                       "multiple of 4096: 2..32 taps in every mode, stable_init designs of 33..2047 taps outside "
                        "RTFB_MODE_SEQUENTIAL)";
     if (bank->groups.size() != 1 || bank->groups[0].cls != kFir) return fail(RTFB_EUNSUPPORTED, what);
     const bool exact = bank->mode == RTFB_MODE_SEQUENTIAL;

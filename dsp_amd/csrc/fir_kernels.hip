@@ -1294,6 +1294,16 @@ static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, siz
                                       long long ramp_first, hipStream_t s);
 static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
                                   double pace_ns, bool tiled, hipStream_t s);
+/* the exact head kernel on the block's first 2048 samples, for the channels inside a partial_init ramp only */
+static hipError_t launch_fir_ramp_heads(const GroupView &g, const BlockIO &io, hipStream_t s)
+{
+    GroupView h = g;
+    h.fir_mfma = 1;                                             /* "others leave at once" */
+    const int total = S + g.kmax - 1;
+    const size_t lds_bytes = (size_t)(total + (total >> 5) + 1) * sizeof(double);
+    hipLaunchKernelGGL(fir_main_kernel<true>, dim3(1, g.count), dim3(kWave), lds_bytes, s, h, io, 0);
+    return hipGetLastError();
+}
 
 hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
 {
@@ -1309,8 +1319,9 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
      * 4.33 TB/s, 16 taps 4.46 -> 4.79, 7 taps 5.03 -> 5.24), otherwise up to 8 taps (5.17 -> 5.24, and the
      * reference's bits); from 9 taps on the matrix-core kernel leads on rows (4.99 against 4.69-4.80).
      * profiles/r3_fir_tile.txt */
-    if (!g.has_partial && g.kmax >= 2 && g.kmax <= 32 && (!g.fir_mfma || g.kmax <= 8) && g.count >= 512 &&
+    if (g.kmax >= 2 && g.kmax <= 32 && (!g.fir_mfma || g.kmax <= 8) && g.count >= 512 &&
         io.aligned16 && io.n % kMfmaSeg == 0 && io.n <= ((size_t)1 << 30)) {
+        if (g.has_partial && (e = launch_fir_ramp_heads(g, io, s)) != hipSuccess) return e;
         if ((e = launch_fir_tile(g, io, 2048, 2048, !g.fir_mfma, 0.0, false, s)) != hipSuccess) return e;
         const int passes = (g.kmax - 1 + kEpiTapPass - 1) / kEpiTapPass;
         const size_t lds_taps = (size_t)(2 * g.kmax + 4) * sizeof(double);
@@ -1523,6 +1534,9 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
     const double *st = g.state + (size_t)gi * g.state_ld;
     const double tail = as_const(st)[K - 1];
     const int t0 = as_const(g.aux)[2 * gi];                     /* 1: the prologue gave sample 0 to stable_init */
+    /* a channel inside a partial_init ramp (ref: src/RTFilter.c:273-297): the exact head kernel has written its
+     * first tile (the ramp is over after K - 1 <= 31 samples); from the second tile on it is in steady state */
+    const bool ramp = as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL && as_const(g.aux)[2 * gi + 1] < K;
     const int nseg = (int)(io.n / 2048);
     const double *src = io.in + (size_t)chan * io.ld_in;        /* tiled layout: ld = 2048, seg_* = nch x 2048; rows: */
     double *dst = io.out + (size_t)chan * io.ld_out;            /* ld = the pitch, seg_* = 2048                      */
@@ -1621,6 +1635,7 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
         if constexpr (kGuard) {                                 /* sample 0 went to stable_init: its output is the sample */
             if (tid == 0 && t0 > 0) y[0] = lo[0];
         }
+        if (kGuard && ramp) return;                             /* (workgroup-uniform) */
         double *ys = xs + kTfLdsDoubles;
 #pragma unroll
         for (int m = 0; m < 4; ++m) *reinterpret_cast<d2 *>(ys + o + 2 * m) = (d2){y[2 * m], y[2 * m + 1]};
@@ -1704,9 +1719,9 @@ static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t 
  * tile (it holds the K-1 samples the state depends on) and the commit.  io.ld_* = 2048. */
 bool fir_tiled_supported(const GroupView &g, size_t n, bool exact)
 {
-    if (g.has_partial || g.kmax < 2 || n == 0 || n % kMfmaSeg || n > ((size_t)1 << 30)) return false;
-    if (g.kmax <= kTfHalo) return true;                         /* the streaming kernel, either arithmetic */
-    return !exact && g.fir_mfma && g.kmax <= 2047;              /* the matrix-core kernel */
+    if (g.kmax < 2 || n == 0 || n % kMfmaSeg || n > ((size_t)1 << 30)) return false;
+    if (g.kmax <= kTfHalo) return true;                         /* the streaming kernel, either arithmetic, either initialiser */
+    return !g.has_partial && !exact && g.fir_mfma && g.kmax <= 2047;    /* the matrix-core kernel, every head folded */
 }
 
 hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in, size_t seg_out, bool exact,
@@ -1717,6 +1732,7 @@ hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (g.kmax <= kTfHalo) {
+        if (g.has_partial && (e = launch_fir_ramp_heads(g, io, s)) != hipSuccess) return e;   /* tile 0: rows a tile wide */
         if ((e = launch_fir_tile(g, io, seg_in, seg_out, exact, pace_ns, true, s)) != hipSuccess) return e;
         BlockIO last = io;                                      /* the block's last tile as a block of its own */
         last.in = io.in + (io.n / 2048 - 1) * seg_in;

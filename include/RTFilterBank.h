@@ -164,13 +164,14 @@ EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
  * is allowed.  dsp_tile_rows / dsp_untile_rows convert between rows (pitch ld) and tiles on the device.
  * Banks wider than the workgroups the GPU holds at once (1024 on MI355X) are launched round by round, 1024
  * channels each: 65 536 x 64K runs at 5.56 TB/s where dense rows give 5.24 (profiles/r3_config4_tiled.txt).
- * _updaten_tiled (not the chained entry) also serves FIR banks: ONE launch group of RTFB_KIND_FIR designs
- * (stable_init), n a multiple of 2 RTFB_TILE, in == out or disjoint.  Up to 32 taps they run on the streaming FIR
+ * _updaten_tiled (not the chained entry) also serves FIR banks: ONE launch group of FIR designs, n a multiple of
+ * 2 RTFB_TILE, in == out or disjoint.  Up to 32 taps (either initialiser) they run on the streaming FIR
  * kernel (one workgroup per channel walking its tiles, round by round on the schedule like the IIR banks):
  * 65 536 x 64K at 32 taps 5.55 TB/s against 5.0 on dense rows, 7 taps 5.95 (profiles/r3_fir_tile.txt).  Its
  * arithmetic is the reference's -- bit-exact -- in RTFB_MODE_SEQUENTIAL and, in the other modes, up to 16 taps
  * (where that costs nothing); 17..32 taps use fused multiply-adds outside RTFB_MODE_SEQUENTIAL (1e-12 class).
- * 33..2047 taps: the matrix-core kernel walks the tiles (not in RTFB_MODE_SEQUENTIAL: RTFB_EUNSUPPORTED).
+ * 33..2047 taps (stable_init designs): the matrix-core kernel walks the tiles (not in RTFB_MODE_SEQUENTIAL:
+ * RTFB_EUNSUPPORTED).
  * Other banks: RTFB_EUNSUPPORTED; a block length that does not fit: RTFB_ESIZE. */
 #define RTFB_TILE 2048
 EXPORT int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream);

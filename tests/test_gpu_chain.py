@@ -181,7 +181,8 @@ def test_tiled_wide_bank_round_by_round_matches_rows_to_the_bit(G, nch, ntiles):
 
 
 @pytest.mark.parametrize("mode", ["auto", "exact"])
-@pytest.mark.parametrize("key,nch", [("fir32_lp_0.25", 40), ("fir7_lp_0.4", 17), ("fir7_lp_0.4", 1), ("fir512_lp_0.25", 6)])
+@pytest.mark.parametrize("key,nch", [("fir32_lp_0.25", 40), ("fir7_lp_0.4", 17), ("fir7_lp_0.4", 1), ("fir512_lp_0.25", 6),
+                                     ("mavg32", 9), ("mavg3", 5)])
 def test_tiled_fir_matches_rows(G, key, nch, mode):
     """FIR banks on the tiled layout: blocks of 2, 4 and 2 tiles, the first on a fresh stream (stable_init), the
     last in place.  Filters of <= 32 taps run on the streaming kernel (fir_tile_kernel): in RTFB_MODE_SEQUENTIAL
@@ -268,7 +269,7 @@ def test_tiled_entry_refuses_what_it_does_not_serve(G):
     seq = _bank(G, "fir512_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)        # > 32 taps: only the matrix cores serve it
     with pytest.raises(Exception):
         seq.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
-    _, b, _ = util.design_coefs("mavg32")
+    _, b, _ = util.design_coefs("mavg512")                  # partial_init with more than 32 taps: no tiled kernel
     ramp = gbank.FilterBank([gbank.fir_design(b, partial=True)], [0] * 4)
     with pytest.raises(Exception):
         ramp.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
