@@ -144,3 +144,47 @@ def test_accessor_header_matches_the_reference_header(tmp_path):
     (tmp_path / "ref").mkdir()
     theirs = _run_accessors(tmp_path / "ref", "/root/reference/include")
     assert mine == theirs
+
+
+DEVICE_API_PROGRAM = r"""
+/* a C99 caller of the additive device headers: compiles, links, and -- without a GPU -- gets clean refusals */
+#include <stdio.h>
+#include <RTFilterBank.h>
+#include <RTFilterStream.h>
+#include <RTFilterDesign.h>
+
+static int my_allgather(void *ctx, const double *send_dev, double *recv_dev, size_t count, void *hip_stream)
+{
+    (void)ctx; (void)send_dev; (void)recv_dev; (void)count; (void)hip_stream;
+    return 0;
+}
+
+int main(void)
+{
+    RTFilterStream_allgather_fn fn = my_allgather;
+    size_t lens[2] = {4096, 4096};
+    /* NULL stream handle: RTFB_EINVAL, nothing touches a device */
+    int rc1 = RTFilterStream_split_updaten(NULL, NULL, NULL, lens, 0, 2, fn, NULL, NULL);
+    int rc2 = RTFilterStream_split_end_state(NULL, 0, 2, fn, NULL, NULL);
+    int rc3 = RTFilterStream_split_updaten_rccl(NULL, NULL, NULL, lens, 0, 2, NULL, NULL);
+    int rc4 = RTFilterBank_updaten_tiled(NULL, NULL, NULL, RTFB_TILE, NULL);
+    printf("%d %d %d %d %d\n", rc1 != 0, rc2 != 0, rc3 != 0, rc4 != 0, RTFB_TILE);
+    return 0;
+}
+"""
+
+
+def test_c_caller_of_the_device_headers(tmp_path):
+    """include/RTFilterBank.h, RTFilterStream.h and RTFilterDesign.h are plain C: a C99 program that uses the
+    round-3 entry points (tiled hand-over, the time split with a caller's all-gather) compiles against them, links
+    with libdsp.so and is refused cleanly on NULL handles."""
+    src = tmp_path / "device_caller.c"
+    exe = tmp_path / "device_caller"
+    src.write_text(DEVICE_API_PROGRAM)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", LIBDIR, "-ldsp", "-lm", "-Wl,--allow-shlib-undefined", "-Wl,-rpath," + LIBDIR]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["1", "1", "1", "1", "2048"]
