@@ -755,7 +755,11 @@ def main_mixed(args, emit=True):
                        "rank0_wave_ms": {k: float(np.mean(v)) for k, v in per_kind.items()},
                        "parallelism": "channel-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("r3_config4_traffic.json")
+                                    if (tiled and wave == 65536 and args.mixed_layout == "sorted") else None,
+                         "traffic_source": "profiles/r3_config4_traffic.json (committed PMC passes of --workload mixed; "
+                                           "per wave, mean of the two kinds; not re-measured by this run)",
                          "algorithmic_bytes_per_launch": samples * BYTES_PER_SAMPLE,
                          "copy_ceiling_measured": copy_gbs,
                          "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,

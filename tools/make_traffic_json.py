@@ -81,7 +81,32 @@ def main():
                "grbm_gui_active_sum_over_8_xcd": m5["GRBM_GUI_ACTIVE"],
                "mfma_pipe_utilisation": m5["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m5["GRBM_GUI_ACTIVE"] / 8)},
               open(os.path.join(ROOT, "profiles", RND + "_config5_traffic.json"), "w"), indent=1)
-    for n in (RND + "_traffic.json", RND + "_fir512_traffic.json", RND + "_config5_traffic.json"):
+    p4 = os.path.join(ROOT, "profiles", RND + "_config4_rocprofv3_summary.txt")
+    names4 = []
+    if os.path.exists(p4):
+        s4 = sections(p4)
+        fi = pick(s4["pmc_fetch"], "iir_pipe_kernel<8, true")
+        ft = pick(s4["pmc_fetch"], "fir_tile_kernel<32")
+        if fi and ft:
+            wi = pick(s4["pmc_write"], "iir_pipe_kernel<8, true")[0]["WRITE_SIZE"]
+            wt = pick(s4["pmc_write"], "fir_tile_kernel<32")[0]["WRITE_SIZE"]
+            rounds = 64                                  # launches of 1024 channels per 65 536-channel wave
+            iir = int((fi[0]["FETCH_SIZE"] * 2 + wi) * 1024) * rounds
+            fir = int((ft[0]["FETCH_SIZE"] * 2 + wt) * 1024) * rounds
+            alg4 = 65536 * 65536 * 16
+            json.dump({"kernels": "one step = one wave of 65 536 channels x 64K in the tiled layout: 64 launches of "
+                                  "iir_pipe_kernel<8,...> (IIR wave) or of fir_tile_kernel<32, false> (FIR wave); the "
+                                  "bench alternates the two kinds, `hbm_bytes_per_launch` is their mean per wave",
+                       "source": "profiles/" + RND + "_config4_rocprofv3_summary.txt (tools/prof.sh: separate --pmc passes; "
+                                 "bench.py --workload mixed --steps 8 --warmup 2 --no-cpu)",
+                       "correction": CORR, "iir_wave_hbm_bytes": iir, "fir_wave_hbm_bytes": fir,
+                       "hbm_bytes_per_launch": (iir + fir) // 2, "algorithmic_bytes_per_launch": alg4,
+                       "traffic_over_algorithmic": (iir + fir) / 2 / alg4,
+                       "note": "the FIR kernel's extra reads are the 32 samples in front of every tile, requested by "
+                               "all 256 threads of a workgroup (16 distinct pieces)"},
+                      open(os.path.join(ROOT, "profiles", RND + "_config4_traffic.json"), "w"), indent=1)
+            names4 = [RND + "_config4_traffic.json"]
+    for n in [RND + "_traffic.json", RND + "_fir512_traffic.json", RND + "_config5_traffic.json"] + names4:
         print(n, json.load(open(os.path.join(ROOT, "profiles", n)))["traffic_over_algorithmic"])
 
 
