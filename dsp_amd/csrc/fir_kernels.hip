@@ -1315,11 +1315,11 @@ hipError_t launch_fir(const GroupView &g, const BlockIO &io, hipStream_t s)
     if (e != hipSuccess) return e;
 
     /* Short filters on whole aligned tiles of a bank wide enough to fill the GPU with one workgroup per channel: the
-     * streaming kernel (rows are tiles a pitch apart) -- in the bit-exact mode always (65 536 x 64K, 32 taps: 3.68 ->
-     * 4.33 TB/s, 16 taps 4.46 -> 4.79, 7 taps 5.03 -> 5.24), otherwise up to 8 taps (5.17 -> 5.24, and the
-     * reference's bits); from 9 taps on the matrix-core kernel leads on rows (4.99 against 4.69-4.80).
-     * profiles/r3_fir_tile.txt */
-    if (g.kmax >= 2 && g.kmax <= 32 && (!g.fir_mfma || g.kmax <= 8) && g.count >= 512 &&
+     * streaming kernel (rows are tiles a pitch apart) -- in the bit-exact mode up to 128 taps (65 536 x 64K, 32 taps:
+     * 3.68 -> 4.33 TB/s, 16 taps 4.46 -> 4.79, 7 taps 5.03 -> 5.24; 16 384 x 64K, 64 taps 2.46 -> 2.78, 128 taps 1.35
+     * -> 1.54), otherwise up to 8 taps (5.17 -> 5.24, and the reference's bits); from 9 taps on the matrix-core
+     * kernel leads on rows (4.99 against 4.69-4.80 at 32 taps, 2.97 against 2.36 at 128).  profiles/r3_fir_tile.txt */
+    if (g.kmax >= 2 && g.kmax <= 128 && (!g.fir_mfma || g.kmax <= 8) && g.count >= 512 &&
         io.aligned16 && io.n % kMfmaSeg == 0 && io.n <= ((size_t)1 << 30)) {
         if (g.has_partial && (e = launch_fir_ramp_heads(g, io, s)) != hipSuccess) return e;
         if ((e = launch_fir_tile(g, io, 2048, 2048, !g.fir_mfma, 0.0, false, s)) != hipSuccess) return e;
@@ -1493,14 +1493,14 @@ static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, siz
 }
 
 /* ------------------------------------------------------------------------ */
-/* Short FIR (2 <= K <= 32 taps, stable_init designs) on the tiled block layout: */
+/* Short FIR (2 <= K <= 128 taps) on the tiled block layout and on rows of wide banks: */
 /* the streaming kernel.  One workgroup of 256 threads per channel walks the      */
 /* channel's tiles in time order -- the access pattern of the pipelined IIR       */
 /* kernel and of its copy twin, which is what the tiled layout and the schedule   */
 /* are made for: two tiles of loads in flight per workgroup, four     */
 /* workgroups per CU, every launch one resident round of channels.  A thread      */
-/* computes 8 consecutive outputs of a tile from LDS (tile + the 32 samples in    */
-/* front of it, 10 doubles per 8 samples: the 64-byte windows of the lanes are    */
+/* computes 8 consecutive outputs of a tile from LDS (tile + the 32 / 64 / 128     */
+/* samples in front of it, 10 doubles per 8 samples: the 64-byte windows are      */
 /* conflict-free), taps oldest first, two 8-sample blocks of the window in        */
 /* registers at a time; the taps are wave-uniform scalars and only the K the      */
 /* design has are ever multiplied: no padding products, so an Inf / NaN reaches   */
@@ -1513,8 +1513,9 @@ static hipError_t launch_fir_nf_fixup(const GroupView &g, const BlockIO &io, siz
 /* bytes per lane (one more barrier per tile) 12.x ms.                             */
 namespace {
 constexpr int kTfThreads = 256;
-constexpr int kTfHalo = 32;                                    /* samples in front of a tile (>= K-1) */
-constexpr int kTfLdsDoubles = (2048 + kTfHalo) / 8 * 10;      /* the tile and the samples in front of it */
+constexpr int kTfMaxTaps = 128;                                /* the widest instantiation */
+constexpr int tf_halo(int kp) { return kp < 32 ? 32 : kp; }    /* samples in front of a tile (>= K-1) */
+constexpr int tf_lds_doubles(int kp) { return (2048 + tf_halo(kp)) / 8 * 10; }  /* the tile and the samples in front of it */
 constexpr int kTfLdsOut = 2048;                                /* behind them: the tile's outputs on their way out */
 }  // namespace
 
@@ -1522,7 +1523,9 @@ template <int KP, bool kExact>
 __global__ void __launch_bounds__(kTfThreads, 4)
 fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out, unsigned int pace_fx)
 {
-    static_assert(KP == 8 || KP == 16 || KP == 32, "window blocks of 8 samples");
+    static_assert(KP == 8 || KP == 16 || KP == 32 || KP == 64 || KP == 128, "window blocks of 8 samples");
+    constexpr int kTfHalo = tf_halo(KP);
+    constexpr int kTfLdsDoubles = tf_lds_doubles(KP);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *xs = reinterpret_cast<double *>(smem_raw);
     const int tid = threadIdx.x;
@@ -1535,14 +1538,23 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
     const double tail = as_const(st)[K - 1];
     const int t0 = as_const(g.aux)[2 * gi];                     /* 1: the prologue gave sample 0 to stable_init */
     /* a channel inside a partial_init ramp (ref: src/RTFilter.c:273-297): the exact head kernel has written its
-     * first tile (the ramp is over after K - 1 <= 31 samples); from the second tile on it is in steady state */
+     * first tile (the ramp is over after K - 1 <= 127 samples); from the second tile on it is in steady state */
     const bool ramp = as_const(g.kind)[dsn] == RTFB_KIND_FIR_PARTIAL && as_const(g.aux)[2 * gi + 1] < K;
     const int nseg = (int)(io.n / 2048);
     const double *src = io.in + (size_t)chan * io.ld_in;        /* tiled layout: ld = 2048, seg_* = nch x 2048; rows: */
     double *dst = io.out + (size_t)chan * io.ld_out;            /* ld = the pitch, seg_* = 2048                      */
-    double bk[KP];
+    /* the taps: up to 32 stay in scalar registers for the whole launch; wider designs read them (scalar loads, the
+     * constant cache holds them) where they are used -- tap by tap behind the branch on K: requested a window block
+     * ahead and without the branch the compiler hoists all of them out of the tile loop and keeps them in lanes of
+     * a vector register (two v_readlane per tap): 2.71 against 2.78 TB/s at 64 taps */
+    constexpr bool kTapsResident = KP <= 32;
+    double bk[kTapsResident ? KP : 1];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) bk[k] = cb[k < K ? k : K - 1];
+    for (int k = 0; k < (kTapsResident ? KP : 1); ++k) bk[k] = cb[k < K ? k : K - 1];
+    auto tap = [&](int kk) -> double {                          /* kk < K */
+        if constexpr (kTapsResident) return bk[kk];
+        else return cb[kk];
+    };
 
     /* Every thread issues the same five loads per tile and the same four stores, whatever the tile: past the end
      * of the block the loads go to the channel's first tile, and all threads fetch a piece of the 32 samples in
@@ -1555,7 +1567,8 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
         const double *p = src + (size_t)sc * seg_in + 2 * tid;
 #pragma unroll
         for (int i = 0; i < 4; ++i) buf[i] = stream_load(reinterpret_cast<const d2 *>(p + 512 * i));
-        h = *reinterpret_cast<const d2 *>(src + (size_t)(sc > 0 ? sc - 1 : 0) * seg_in + (2048 - kTfHalo) + 2 * (tid & 15));
+        h = *reinterpret_cast<const d2 *>(src + (size_t)(sc > 0 ? sc - 1 : 0) * seg_in + (2048 - kTfHalo) +
+                                          2 * (tid & (kTfHalo / 2 - 1)));
     };
     /* sample i of the tile (i >= -32) sits at LDS double (i + 32) + 2 ((i + 32) >> 3) */
     auto stage = [&](const d2(&buf)[4], const d2 &h, bool first) {
@@ -1604,7 +1617,7 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
             for (int kk = -8 * q; kk >= -8 * q - 7; --kk) {
                 if (kk > KP - 1) continue;
                 if (kk < K) {                                   /* wave-uniform */
-                    const double t = bk[kk];
+                    const double t = tap(kk);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int idx = j - kk - 8 * q;         /* 0 .. 14 within (lo, hi) */
@@ -1624,13 +1637,14 @@ fir_tile_kernel(GroupView g, BlockIO io, int gi0, size_t seg_in, size_t seg_out,
             for (int j = 0; j < 8; ++j) lo[j] = hi[j];
         }
         double y[8];
+        const double b0 = tap(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if constexpr (kExact) {
-                const double pr = lo[j] * bk[0];
+                const double pr = lo[j] * b0;
                 y[j] = pr + acc[j];
             } else
-                y[j] = __builtin_fma(lo[j], bk[0], acc[j]);
+                y[j] = __builtin_fma(lo[j], b0, acc[j]);
         }
         if constexpr (kGuard) {                                 /* sample 0 went to stable_init: its output is the sample */
             if (tid == 0 && t0 > 0) y[0] = lo[0];
@@ -1688,7 +1702,8 @@ static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t 
     /* one resident round (4 workgroups per CU) per launch, so that the workgroups of a launch stay in step; short
      * blocks (under 12 tiles: mostly pipeline fill, never paced) go as one launch */
     const int round = io.n / 2048 >= 12 ? 1024 : (g.count > 1024 ? g.count : 1024);
-    const size_t lds = (size_t)(kTfLdsDoubles + kTfLdsOut) * sizeof(double);
+    const int kp = g.kmax <= 8 ? 8 : g.kmax <= 16 ? 16 : g.kmax <= 32 ? 32 : g.kmax <= 64 ? 64 : 128;
+    const size_t lds = (size_t)(tf_lds_doubles(kp) + kTfLdsOut) * sizeof(double);
     for (int off = 0; off < g.count; off += round) {
         const int cnt = g.count - off < round ? g.count - off : round;
         unsigned int pace_fx = 0;
@@ -1703,9 +1718,11 @@ static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t 
     else                                                                                                            \
         hipLaunchKernelGGL((fir_tile_kernel<KP, false>), dim3(cnt), dim3(kTfThreads), lds, s, g, io, off, seg_in,   \
                            seg_out, pace_fx);
-        if (g.kmax <= 8) { DSP_TF(8) }
-        else if (g.kmax <= 16) { DSP_TF(16) }
-        else { DSP_TF(32) }
+        if (kp == 8) { DSP_TF(8) }
+        else if (kp == 16) { DSP_TF(16) }
+        else if (kp == 32) { DSP_TF(32) }
+        else if (kp == 64) { DSP_TF(64) }
+        else { DSP_TF(128) }
 #undef DSP_TF
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1717,10 +1734,19 @@ static hipError_t launch_fir_tile(const GroupView &g, const BlockIO &io, size_t 
  * (no partial_init channels, 2 <= K <= 2047) and n a multiple of the 4096-output item: prologue (sample 0 of a
  * reset stream sits at the same place in both layouts), ONE persistent launch, the end state from the block's last
  * tile (it holds the K-1 samples the state depends on) and the commit.  io.ld_* = 2048. */
+/* Which kernel serves a group on the tiled layout: the streaming kernel up to 128 taps -- except where the matrix-core
+ * kernel may run (AUTO, no partial_init channel) and is faster, from 33 taps on (16 384 x 64K, fused arithmetic against
+ * matrix cores: 48 taps 4.66 / 4.78 TB/s, 64 taps 4.07 / 4.28, 128 taps 2.39 / 2.97; profiles/r3_fir_tile.txt). */
+static bool tf_serves_tiled(const GroupView &g, bool exact)
+{
+    const bool mfma_can = !g.has_partial && !exact && g.fir_mfma;
+    return g.kmax <= kTfMaxTaps && (!mfma_can || g.kmax <= 32);
+}
+
 bool fir_tiled_supported(const GroupView &g, size_t n, bool exact)
 {
     if (g.kmax < 2 || n == 0 || n % kMfmaSeg || n > ((size_t)1 << 30)) return false;
-    if (g.kmax <= kTfHalo) return true;                         /* the streaming kernel, either arithmetic, either initialiser */
+    if (tf_serves_tiled(g, exact)) return true;                 /* the streaming kernel, either arithmetic, either initialiser */
     return !g.has_partial && !exact && g.fir_mfma && g.kmax <= 2047;    /* the matrix-core kernel, every head folded */
 }
 
@@ -1731,7 +1757,7 @@ hipError_t launch_fir_tiled(const GroupView &g, const BlockIO &io, size_t seg_in
     hipLaunchKernelGGL(fir_prologue_kernel, dim3(pro_blocks), dim3(256), 0, s, g, io);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (g.kmax <= kTfHalo) {
+    if (tf_serves_tiled(g, exact)) {
         if (g.has_partial && (e = launch_fir_ramp_heads(g, io, s)) != hipSuccess) return e;   /* tile 0: rows a tile wide */
         if ((e = launch_fir_tile(g, io, seg_in, seg_out, exact, pace_ns, true, s)) != hipSuccess) return e;
         BlockIO last = io;                                      /* the block's last tile as a block of its own */

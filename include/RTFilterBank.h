@@ -73,7 +73,9 @@ typedef struct RTFilterDesign {
  *             Toeplitz-tile FP64 MFMA kernel (4.9 TB/s at any short length, where the bit-exact kernel
  *             falls from 4.7 at 2 taps to 3.5 at 32); short blocks on wide banks (>= 16384 channels,
  *             <= 4096 samples, <= 32 taps) stay on the bit-exact lane-per-channel kernel in every mode.
- * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel.
+ * SEQUENTIAL  bit-exact kernels only (reference operation order) for every channel (FIR of <= 128 taps on banks
+ *             of >= 512 channels and whole 4096-sample pieces: the streaming kernel, 4.4 TB/s at 32 taps, 2.8 at
+ *             64, 1.5 at 128, where the unfused arithmetic is the bound).
  * SCAN        like AUTO but IIR channels always on the scan kernels: the conditioning probe is bypassed, and with
  *             it every accuracy promise -- the re-associated arithmetic then sits at the design's own conditioning
  *             floor, which can be far above 1e-12 (19 of 200 random Butterworth designs of orders 10..16 exceeded
@@ -170,8 +172,10 @@ EXPORT size_t RTFilterBank_noalloc_max_doubles(void);
  * 65 536 x 64K at 32 taps 5.55 TB/s against 5.0 on dense rows, 7 taps 5.95 (profiles/r3_fir_tile.txt).  Its
  * arithmetic is the reference's -- bit-exact -- in RTFB_MODE_SEQUENTIAL and, in the other modes, up to 16 taps
  * (where that costs nothing); 17..32 taps use fused multiply-adds outside RTFB_MODE_SEQUENTIAL (1e-12 class).
- * 33..2047 taps (stable_init designs): the matrix-core kernel walks the tiles (not in RTFB_MODE_SEQUENTIAL:
- * RTFB_EUNSUPPORTED).
+ * 33..128 taps: the same kernel where the matrix cores may not run -- RTFB_MODE_SEQUENTIAL (bit-exact) and banks
+ * with a partial_init design (fused outside RTFB_MODE_SEQUENTIAL).  33..2047 taps otherwise (stable_init designs,
+ * not RTFB_MODE_SEQUENTIAL): the matrix-core kernel walks the tiles.  Above 128 taps RTFB_MODE_SEQUENTIAL and
+ * partial_init banks get RTFB_EUNSUPPORTED.
  * Other banks: RTFB_EUNSUPPORTED; a block length that does not fit: RTFB_ESIZE. */
 #define RTFB_TILE 2048
 EXPORT int RTFilterBank_updaten_tiled(RTFilterBank *bank, double *out, const double *in, size_t n, void *hip_stream);

@@ -185,7 +185,7 @@ def test_tiled_wide_bank_round_by_round_matches_rows_to_the_bit(G, nch, ntiles):
                                      ("mavg32", 9), ("mavg3", 5)])
 def test_tiled_fir_matches_rows(G, key, nch, mode):
     """FIR banks on the tiled layout: blocks of 2, 4 and 2 tiles, the first on a fresh stream (stable_init), the
-    last in place.  Filters of <= 32 taps run on the streaming kernel (fir_tile_kernel): in RTFB_MODE_SEQUENTIAL
+    last in place.  Filters of <= 128 taps run on the streaming kernel (fir_tile_kernel): in RTFB_MODE_SEQUENTIAL
     with the reference's arithmetic -- the BITS of the rows entry in that mode and of the oracle --, in AUTO with
     fused multiply-adds (within 1e-12).  Longer filters run on the matrix-core kernel in AUTO (the bits of
     RTFilterBank_updaten in AUTO) and are refused in SEQUENTIAL.  The carried delay line is bit-exact in every case."""
@@ -196,7 +196,7 @@ def test_tiled_fir_matches_rows(G, key, nch, mode):
     K = len(util.design_coefs(key)[1])
     blocks = [2 * gbank.TILE, 4 * gbank.TILE, 2 * gbank.TILE]
     a_bank, b_bank = _bank(G, key, nch, mode=m), _bank(G, key, nch, mode=m)
-    if exact and K > 32:
+    if exact and K > 128:
         x = torch.zeros((nch, blocks[0]), dtype=torch.float64, device="cuda")
         with pytest.raises(Exception):
             b_bank.updaten_tiled_ptr(x.data_ptr(), x.data_ptr(), blocks[0])
@@ -209,7 +209,7 @@ def test_tiled_fir_matches_rows(G, key, nch, mode):
         yt = xt if i == 2 else torch.empty_like(xt)
         b_bank.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
         got = gbank.untile_rows(yt)
-        if exact or K > 32:
+        if exact or K > 128:
             assert torch.equal(got, want), (key, i)
         else:
             assert util.rel_to_peak(got.cpu().numpy(), want.cpu().numpy()).max() <= TOL, (key, i)
@@ -258,6 +258,40 @@ def test_tiled_fir_wide_bank(G):
         assert util.rel_to_peak(got, want_o) <= TOL, c
 
 
+@pytest.mark.parametrize("mode", ["auto", "exact"])
+@pytest.mark.parametrize("K,partial,nch", [(33, False, 9), (64, False, 40), (64, True, 5), (100, False, 17), (128, False, 12),
+                                           (128, True, 3)])
+def test_tiled_fir_streaming_kernel_33_to_128_taps(G, K, partial, nch, mode):
+    """The 64- and 128-tap instantiations of the streaming kernel (halo of 64 / 128 samples in front of a tile, taps
+    read where they are used), stable_init and partial_init ramps, two designs of different lengths in one group:
+    the oracle's bits in RTFB_MODE_SEQUENTIAL, within 1e-12 with fused multiply-adds in AUTO; a fresh stream, a
+    carried block, an in-place block; the delay line bit-exact."""
+    import torch
+    from dsp_amd import bank as gbank
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000 + K)
+    ds = [gbank.fir_design(rng.normal(size=K) / K ** 0.5, partial=partial),
+          gbank.fir_design(rng.normal(size=K - 20) / K ** 0.5, partial=False)]
+    cmap = [c % 2 for c in range(nch)]
+    gb = gbank.FilterBank(ds, cmap, mode=gbank.MODE_SEQUENTIAL if mode == "exact" else gbank.MODE_AUTO)
+    ob = orc.Bank([G.to_orc_design(d) for d in ds], cmap)
+    pos = 0
+    for i, n in enumerate([2 * gbank.TILE, 4 * gbank.TILE, 2 * gbank.TILE]):
+        x = G.make_inputs(79, nch, n, pos)
+        want = ob.updaten(x, threads=4)
+        xt = gbank.tile_rows(G.to_dev(x))
+        yt = xt if i == 2 else torch.empty_like(xt)
+        gb.updaten_tiled_ptr(yt.data_ptr(), xt.data_ptr(), n)
+        got = gbank.untile_rows(yt).cpu().numpy()
+        if mode == "exact":
+            assert util.bits_equal(got, want), (K, i)
+        else:
+            assert util.rel_to_peak(got, want).max() <= TOL, (K, i)
+        st = gb.get_state()
+        assert util.bits_equal(st[0][:, :ob.state.shape[1]], ob.state) and np.array_equal(st[2], ob.init)
+        pos += n
+
+
 def test_tiled_entry_refuses_what_it_does_not_serve(G):
     import torch
     from dsp_amd import bank as gbank
@@ -266,10 +300,10 @@ def test_tiled_entry_refuses_what_it_does_not_serve(G):
     fir = _bank(G, "fir32_lp_0.25", 4)
     with pytest.raises(Exception):                          # one tile: not a multiple of the 4096-output item
         fir.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), gbank.TILE)
-    seq = _bank(G, "fir512_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)        # > 32 taps: only the matrix cores serve it
+    seq = _bank(G, "fir512_lp_0.25", 4, mode=gbank.MODE_SEQUENTIAL)        # > 128 taps: only the matrix cores serve it
     with pytest.raises(Exception):
         seq.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)
-    _, b, _ = util.design_coefs("mavg512")                  # partial_init with more than 32 taps: no tiled kernel
+    _, b, _ = util.design_coefs("mavg512")                  # partial_init with more than 128 taps: no tiled kernel
     ramp = gbank.FilterBank([gbank.fir_design(b, partial=True)], [0] * 4)
     with pytest.raises(Exception):
         ramp.updaten_tiled_ptr(y.data_ptr(), x.data_ptr(), 2 * gbank.TILE)

@@ -381,21 +381,24 @@ def test_mfma_path_confines_inf_and_nan_to_the_outputs_the_reference_reaches(G, 
 
 
 @pytest.mark.parametrize("key,mode", [("fir32_lp_0.25", "exact"), ("fir7_lp_0.4", "exact"), ("fir7_lp_0.4", "auto"),
-                                      ("rand16", "exact"), ("rand2", "auto"), ("mavg32", "exact"), ("mavg3", "auto")])
+                                      ("rand16", "exact"), ("rand2", "auto"), ("mavg32", "exact"), ("mavg3", "auto"),
+                                      ("rand33", "exact"), ("rand64", "exact"), ("rand100", "exact"), ("rand128", "exact"),
+                                      ("ramp77", "exact"), ("rand129", "exact")])
 def test_streaming_kernel_on_rows_of_a_wide_bank(G, key, mode):
-    """fir_tile_kernel on dense rows (banks of >= 512 channels, whole 4096-sample pieces, <= 32 taps: always in
-    RTFB_MODE_SEQUENTIAL, up to 8 taps in AUTO): the reference's bits against the oracle on every channel, over a
+    """fir_tile_kernel on dense rows (banks of >= 512 channels, whole 4096-sample pieces, <= 128 taps: always in
+    RTFB_MODE_SEQUENTIAL, up to 8 taps in AUTO; 129 taps: the kernels that serve every length): the reference's
+    bits against the oracle on every channel, over a
     fresh stream (stable_init), carried blocks, an in-place block and a ragged block in between (which the other
     kernels take); unaligned row pitch falls back as well."""
     import torch
     from dsp_amd import bank as gbank
     from oracle import oracle as orc
     nch = 600
-    if key.startswith("rand"):
+    if key.startswith(("rand", "ramp")):
         b = np.random.default_rng(9).normal(size=int(key[4:])) / int(key[4:])
     else:
         b = util.design_coefs(key)[1]
-    d = gbank.fir_design(b, partial=key.startswith("mavg"))          # moving averages ramp up with partial_init
+    d = gbank.fir_design(b, partial=key.startswith(("mavg", "ramp")))     # moving averages ramp up with partial_init
     gb = gbank.FilterBank([d], [0] * nch, mode=gbank.MODE_SEQUENTIAL if mode == "exact" else gbank.MODE_AUTO)
     ob = orc.Bank([G.to_orc_design(d)], [0] * nch)
     pos = 0

@@ -18,7 +18,7 @@ for c in range(cases):
     K = max(Ks)
     partial = bool(rng.random() < 0.3)
     nch = int(rng.choice([1, 3, 64, 130])) if K <= 1024 else int(rng.choice([1, 3, 9]))
-    if K <= 33 and rng.random() < 0.5:
+    if K <= 255 and rng.random() < 0.5:
         nch = int(rng.choice([512, 600, 1100]))              # wide enough for the streaming kernel (fir_tile_kernel)
     blocks = [int(rng.choice([1, 7, 100, 2048, 4095, 4096, 4097, 4096 + 5, 8191, 8192, 8192 + 16, 12288 + 2047, 16384, 20000]))
               for _ in range(int(rng.integers(2, 5)))]
