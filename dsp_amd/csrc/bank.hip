@@ -3065,7 +3065,7 @@ int RTFilterStream_split_updaten(RTFilterStream *st, double *out, const double *
                 return rc;
         } else if ((rc = RTFilterStream_import_state(st, all + (size_t)(rank - 1) * row, s)))
             return rc;
-        if ((rc = RTFilterStream_updaten(st, out, in, n, s))) return rc;
+        if (n && (rc = RTFilterStream_updaten(st, out, in, n, s))) return rc;     /* (a last rank may hold nothing) */
     } else {
         if (st->split_carry_remote) {                       /* rank 0 needs its start state before its pass */
             if ((rc = RTFilterStream_export_state(st, mine + plen, s)) || (rc = gather())) return rc;
@@ -3090,7 +3090,7 @@ int RTFilterStream_split_updaten(RTFilterStream *st, double *out, const double *
         if ((rc = gather())) return rc;
         if (rank > 0) {
             if ((rc = RTFilterStream_compose_state(st, all, row, (size_t)rank, lens[1], s)) ||
-                (rc = RTFilterStream_updaten(st, out, in, n, s)))
+                (n && (rc = RTFilterStream_updaten(st, out, in, n, s))))
                 return rc;
         }
     }
