@@ -475,6 +475,7 @@ struct Group {
     bool scan_safe = false;             /* kIirFast: every design passed the conditioning probe */
     bool has_tables = true;             /* kIirFast: every design carries its scan tables          */
     bool unit_a0 = false;               /* kIirFast: every design has a[0] == 1.0               */
+    bool even_b = true;                 /* kIirFast: every design has b[odd] == 0 exactly       */
     int sos_sections = 0;               /* kIirFast: > 0 = fused cascades of this many sections (order = 2 x that) */
     std::vector<int32_t> chans;         /* global channel ids, ascending */
     std::vector<int32_t> chan_design;   /* design index per entry of chans (a section's design for SOS channels) */
@@ -540,6 +541,8 @@ struct RTFilterBank {
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
     double *d_static_scratch = nullptr;   /* this device's copy of `scratch` (RTFilterBank_updaten_noalloc) */
+    bool stream_rows = false;             /* set by RTFilterStream around one call: the rows are consecutive sub-chunks
+                                             of one stream, the order 9..16 scan kernel runs its own run-ups (BlockIO::runup) */
     HostPipe host;                        /* staging rings of RTFilterBank_updaten_host, built on first use */
 };
 
@@ -1263,6 +1266,11 @@ int finish_bank(RTFilterBank *bk, const std::vector<double> &init_state,
             g.state_ld = std::max(g.state_ld, d.state_slots());
             g.levels2_max = std::max(g.levels2_max, d.levels2);
             if (d.fast() && !d.has_tables) g.has_tables = false;
+            if (g.cls == kIirFast && g.even_b) {
+                if (d.sos_fused) g.even_b = false;
+                for (size_t i = 1; i < d.b.size() && g.even_b; i += 2)
+                    if (d.b[i] != 0.0) g.even_b = false;
+            }
             if (d.kind != RTFB_KIND_IIR && !d.sos_fused) g.kmax = std::max(g.kmax, d.nb);
             if (d.kind == RTFB_KIND_FIR_PARTIAL) g.has_partial = true;
             if (g.single_design == -2) g.single_design = di;
@@ -1337,6 +1345,7 @@ GroupView view_of(const RTFilterBank *bk, const Group &g)
     v.aux = g.d_aux;
     v.kmax = g.kmax;
     v.unit_a0 = g.unit_a0 ? 1 : 0;
+    v.even_b = (g.cls == kIirFast && g.even_b) ? 1 : 0;
     v.fir_mfma = 0;
     v.has_partial = g.has_partial ? 1 : 0;
     v.single_design = g.single_design;
@@ -1855,6 +1864,17 @@ int RTFilterBank_set_mode(RTFilterBank *bank, int mode)
     return RTFB_OK;
 }
 
+/* Does a call of n samples per row on this one-group bank go to iir_scan16_kernel on whole aligned segments?  (The
+ * dispatch below, restated for RTFilterStream, which may then leave the run-ups of its sub-chunks to that kernel.) */
+static bool scan16_serves(const RTFilterBank *bank, size_t n)
+{
+    if (bank->groups.size() != 1) return false;
+    const Group &g = bank->groups[0];
+    if (g.cls != kIirFast || g.sos_sections || g.order <= kScan2MaxOrder || !iir_scan_supported(g.order)) return false;
+    if (bank->mode == RTFB_MODE_SEQUENTIAL || !g.has_tables || (bank->mode == RTFB_MODE_AUTO && !g.scan_safe)) return false;
+    return !pipe16_enabled() && n >= (size_t)kWave * kScanT && n % ((size_t)kWave * kScanT) == 0;
+}
+
 static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const double *in,
                         size_t ld_in, size_t n, void *hip_stream, bool no_alloc)
 {
@@ -1879,6 +1899,8 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
         int rc = chain_close(bank, s);
         if (rc) return rc;
     }
+    if (bank->stream_rows && !(scan16_serves(bank, n) && io.aligned16))       /* before anything is enqueued */
+        return fail(RTFB_EINVAL, "internal: stream rows handed to a call the order 9..16 scan kernel does not serve whole");
     const double *in_end = in + (bank->nch - 1) * ld_in + n;
     const double *out_end = out + (bank->nch - 1) * ld_out + n;
     const bool overlap = in < out_end && out < in_end;
@@ -1963,7 +1985,10 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
         else if (g.order <= kScan2MaxOrder) HIP_TRY(launch_iir_scan2(g.order, v, io, s));   /* > 1024 designs */
         else if (pipe16_enabled() && io.aligned16 && n % kPipe16Seg == 0)
             HIP_TRY(launch_iir_pipe16(g.order, v, io, Pipe16Ext{}, 0, s));   /* orders 9..16, whole segments */
-        else HIP_TRY(launch_iir_scan(g.order, v, io, s));           /* orders 9..16, any shape */
+        else {
+            io.runup = bank->stream_rows ? 1 : 0;                   /* (checked above) */
+            HIP_TRY(launch_iir_scan(g.order, v, io, s));            /* orders 9..16, any shape */
+        }
     }
     return RTFB_OK;
 }
@@ -2414,8 +2439,21 @@ int RTFilterBank_sync_to_host(RTFilterBank *bank, void *hip_stream)
 
 namespace {
 
-constexpr size_t kStreamMaxSplit = 1024;      /* sub-chunks per call at most: the 1024 workgroups (4 per CU) the GPU holds at
-                                                 once; with 2048 the second half only starts as the first drains: -1.2 % */
+constexpr size_t kStreamMaxSplit = 1024;      /* sub-chunks per call at most while they are long: the 1024 workgroups (4
+                                                 per CU) the GPU holds at once; with 2048 the second half only starts as
+                                                 the first drains: -1.2 % */
+/* Long streams: MORE, SHORTER sub-chunks.  1024 sub-chunks of a 2^30-sample stream are 1024 windows 8 MiB apart, each
+ * on its own pages, read and written: a plain copy with that pattern reaches 4.85-5.17 TB/s (tools/
+ * stream16_copy_ceiling.py), and the order-16 kernel runs at exactly that, 4.94.  Sub-chunks of 2^17 samples, taken
+ * by the workgroups in dispatch order, 1024 at a time, make the resident workgroups sweep ONE window of 1 GiB that
+ * slides along the stream: 5.27 TB/s (2^18: 5.20, 2^16: 5.23, 2^14: 4.95 -- a workgroup's first segment is not
+ * overlapped; tools/stream16_split_shape.py; config 5 end to end by sub-chunk length: 2^15 310 000 Msamples/s, 2^16
+ * 319 500, 2^17 326 000, 2^18 322 400, 2^19 318 300).  A run-up LAUNCH over 8191 sub-chunks (one short ragged segment per
+ * workgroup, eight rounds of them) costs more than that gains (config 5: 310 000 -> 292 000 Msamples/s), so the
+ * scan kernel of orders 9..16 computes the run-ups itself (BlockIO::runup, kernels.hip). */
+constexpr size_t kStreamChunkTarget = (size_t)1 << 17;
+constexpr size_t kStreamMaxSplitShort = 65536;
+constexpr size_t kScanSeg = (size_t)kWave * kScanT;           /* iir_scan16_kernel's segment: its run-up length */
 constexpr size_t kStreamMinSplit = 8;         /* below this the sequential path is as good */
 constexpr size_t kStreamGrain = 2048;         /* sub-chunk lengths are multiples of the scan segment */
 constexpr size_t kStreamMaxDecay = (size_t)1 << 20;
@@ -2539,15 +2577,28 @@ int stream_scratch(RTFilterStream *st, size_t doubles, hipStream_t s)
 }
 
 /* One time-split piece: in[0 .. C*Lc) as C channels of Lc samples. */
-int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t C, size_t Lc, hipStream_t s)
+int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t C, size_t Lc, bool self_runup,
+                       hipStream_t s)
 {
     SplitBanks *sb = nullptr;
     int rc = split_banks(st, C, &sb);
     if (rc) return rc;
     const size_t M = st->decay;
-    if ((rc = stream_scratch(st, (C - 1) * M, s))) return rc;
     Group &gm = sb->main->groups[0], &gw = sb->warm->groups[0], &g1 = st->one->groups[0];
     const size_t ld = (size_t)gm.state_ld;
+    if (self_runup) {
+        /* sub-chunk 0 takes the carried state; the kernel gives every other one the zero-state response of the
+         * segment in front of it (no run-up launch, no scratch) */
+        HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, nullptr, C, (int)ld,
+                                  0, 1, s));
+        sb->main->stream_rows = true;
+        rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s);
+        sb->main->stream_rows = false;
+        if (rc) return rc;
+        HIP_TRY(launch_split_finish(g1.d_state, g1.d_fval, g1.d_init, gm.d_state, gm.d_fval, C, (int)ld, s));
+        return RTFB_OK;
+    }
+    if ((rc = stream_scratch(st, (C - 1) * M, s))) return rc;
 
     /* run-ups: channel c-1 of `warm` filters the M samples in front of sub-chunk c from the zero state */
     HIP_TRY(launch_split_zero(gw.d_state, gw.d_init, C - 1, (int)ld, s));
@@ -2818,6 +2869,16 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
         size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
+        /* long streams of orders 9..16: more, shorter sub-chunks whose run-ups the kernel does itself (it reads the
+         * segment in front of a sub-chunk: not in place, where that segment may already hold outputs) */
+        bool self_runup = false;
+        size_t grain = kStreamGrain;
+        if (st->decay && st->decay <= kScanSeg && whole16 && !overlap && scan16_serves(st->one, kScanSeg) &&
+            st->one->groups[0].scan_safe && n / std::max(lmin, kStreamChunkTarget) > kStreamMaxSplit) {
+            C = std::min(kStreamMaxSplitShort, n / std::max(lmin, kStreamChunkTarget));
+            self_runup = true;
+            grain = kScanSeg;
+        }
         bool exact = false;
         if (C < kStreamMinSplit && st->exact_ok && !overlap) {
             /* no (usable) decay: compose the chunk maps exactly instead of falling to one workgroup.  A stream
@@ -2842,10 +2903,11 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
             if (rc) return rc;
             break;
         }
-        const size_t Lc = n / C / kStreamGrain * kStreamGrain;
+        const size_t Lc = n / C / grain * grain;
         if (first) st->last_split = C;
         first = false;
-        int rc = exact ? stream_split_piece_exact(st, out, in, C, Lc, s) : stream_split_piece(st, out, in, C, Lc, s);
+        int rc = exact ? stream_split_piece_exact(st, out, in, C, Lc, s)
+                       : stream_split_piece(st, out, in, C, Lc, self_runup, s);
         if (rc) return rc;
         out += C * Lc;
         in += C * Lc;

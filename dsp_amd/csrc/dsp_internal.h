@@ -58,6 +58,9 @@ struct GroupView {
     const int32_t *gtab_off;  /* per design: offset in pows of G[n][i] = (A^(31-n) B)_i, n < 32,
                                  followed by Gc[i] = (sum_m A^m e_{N-1})_i                  */
     int32_t        levels2_max;   /* largest levels2 in the group                          */
+    int32_t        even_b;        /* IIR fast groups: b[1], b[3], ... are exactly zero in every design (every
+                                     band-pass from the bilinear transform: numerator k (z^2 - 1)^n) -- the
+                                     re-associated kernels of orders 9..16 then issue no multiply-add for them */
     const int32_t *levels1;   /* per design: combine levels of the one-wave kernel (A^(64 2^k)) that matter */
     const int32_t *gtab1_off; /* per design: offset in pows of the one-wave kernel's zero-state table:
                                  G[n][i] = (A^(63-n) B)_i, n < 64, followed by Gc[i]            */
@@ -75,6 +78,9 @@ struct BlockIO {
     size_t        ld_in;
     size_t        n;
     int           aligned16;  /* in/out/ld allow 16-byte vector access */
+    int           runup = 0;  /* iir_scan16_kernel only (RTFilterStream): the rows are consecutive sub-chunks of one
+                                 stream; every channel but the first starts from the zero-state response of the 4096
+                                 samples in front of its row (kernels.hip).  0 everywhere else. */
 };
 
 /* Chained launches of the pipelined kernel (RTFilterBank_updaten_chained): consecutive blocks of a bank are
