@@ -876,13 +876,12 @@ def main_stream16(args, emit=True):
                        "parallelism": "time-split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (2 * measured_traffic("r3_config5_traffic.json")
-                                     if world == 1 and args.stream_log2 == 30
-                                     and measured_traffic("r3_config5_traffic.json") else None),
+                         "traffic": (measured_traffic("r3_config5_traffic.json")
+                                     if world == 1 and args.stream_log2 == 30 else None),
                          "algorithmic_bytes_per_launch": n * BYTES_PER_SAMPLE,
-                         "note": "per-GPU bytes of one step (the run-up launch over the sub-chunks' tails, the main "
-                                 "launch of the scan kernel over all sub-chunks, state copies) over the step's device "
-                                 "time on rank 0; traffic = PMC bytes of the two launches "
+                         "note": "per-GPU bytes of one step (ONE launch of the scan kernel over all sub-chunks -- it "
+                                 "computes their run-ups itself --, two small state kernels) over the step's device "
+                                 "time on rank 0; traffic = PMC bytes of that launch "
                                  "(profiles/r3_config5_traffic.json, committed; not re-measured by this run)",
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }

@@ -2448,7 +2448,9 @@ constexpr size_t kStreamMaxSplit = 1024;      /* sub-chunks per call at most whi
  * by the workgroups in dispatch order, 1024 at a time, make the resident workgroups sweep ONE window of 1 GiB that
  * slides along the stream: 5.27 TB/s (2^18: 5.20, 2^16: 5.23, 2^14: 4.95 -- a workgroup's first segment is not
  * overlapped; tools/stream16_split_shape.py; config 5 end to end by sub-chunk length: 2^15 310 000 Msamples/s, 2^16
- * 319 500, 2^17 326 000, 2^18 322 400, 2^19 318 300).  A run-up LAUNCH over 8191 sub-chunks (one short ragged segment per
+ * 319 500, 2^17 326 000, 2^18 322 400, 2^19 318 300; one resident round of waves walking the sub-chunks with the
+ * prefetch running across them instead of a wave per sub-chunk: the same 326 600 at 2^17, less at every other
+ * length -- not kept).  A run-up LAUNCH over 8191 sub-chunks (one short ragged segment per
  * workgroup, eight rounds of them) costs more than that gains (config 5: 310 000 -> 292 000 Msamples/s), so the
  * scan kernel of orders 9..16 computes the run-ups itself (BlockIO::runup, kernels.hip). */
 constexpr size_t kStreamChunkTarget = (size_t)1 << 17;

@@ -160,6 +160,49 @@ def test_stream_from_filter_and_sync_to_host(G):
     fs.close()
 
 
+@pytest.mark.parametrize("design", ["bw8", "lp11"])
+def test_long_stream_in_short_sub_chunks_with_in_kernel_run_ups(G, design):
+    """Streams of orders 9..16 longer than 1024 x 2^17 samples are cut into sub-chunks of 2^17 samples whose start
+    states iir_scan16_kernel computes itself (the zero-state response of the 4096 samples in front of each).  Config
+    5's band-pass (numerator taps b[odd] == 0: the even-b instantiation) and an order-11 low-pass (no zero taps):
+    a fresh stream, a ragged continuation, and an in-place call (which must fall back to the run-up launch: the
+    samples in front of a sub-chunk would already be outputs) -- all within 1e-12 of the oracle, state included."""
+    import torch
+    from dsp_amd import bank as gbank
+    from dsp_amd import dsp
+    from dsp_amd import stream as gstream
+    from oracle import oracle as orc
+    if design == "bw8":
+        b, a = _bw8()
+        assert all(v == 0.0 for v in b[1::2])
+    else:
+        f = dsp.butterworth(11, 0.0, 0.35)
+        b, a = np.array(f.b()), np.array(f.a())
+    fs = gstream.FilterStream(gbank.iir_design(b, a))
+    assert 0 < fs.decay_length <= 4096
+    ref = orc.iir(b, a)
+    pos = 0
+    for i, n in enumerate(((1 << 27) + 3 * (1 << 17) + 777, (1 << 27) + (1 << 18), (1 << 27) + (1 << 18))):
+        x = util.synth(91, 0, pos, n)
+        want = ref.updaten(x)
+        xd = torch.from_numpy(x).cuda()
+        if i == 2:
+            fs.updaten_ptr(xd.data_ptr(), xd.data_ptr(), n)
+            yd = xd
+            assert fs.last_split == 1024, fs.last_split
+        else:
+            yd = fs(xd)
+            assert fs.last_split > 1024, fs.last_split
+        got = yd.cpu().numpy()
+        del xd, yd
+        assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want)), (design, i)
+        st, fv, ini = fs.get_state()
+        assert np.max(np.abs(st[:len(ref.state)] - ref.state)) <= TOL * max(1.0, np.max(np.abs(ref.state)))
+        assert abs(fv - ref.filtered_value) <= TOL * max(1.0, abs(ref.filtered_value)) and ini == 0
+        pos += n
+    fs.close()
+
+
 def _resonator(radius=0.9999, theta=0.3 * np.pi):
     """Second-order resonator with its pole pair at `radius`: well conditioned (passes the scan probe) and slow to
     forget -- radius^M < 2^-80 needs M = 5.5e5 samples, so the decay shortcut cannot split a 2^24-sample call."""

@@ -68,10 +68,14 @@ def main():
     w5 = pick(s5["pmc_write"], "iir_scan16_kernel")[0]["WRITE_SIZE"]
     m5 = pick(s5["pmc_mfma"], "iir_scan16_kernel")[0]
     hbm5 = int(f5 * 1024 * 2 + w5 * 1024)
-    alg5 = (1 << 29) * 16          # half a step: the means are over two launches
-    json.dump({"kernel": "dsp::iir_scan16_kernel<16, 64, true, false>: mean over the two launches of a config-5 step "
-                         "(run-up over the sub-chunks' 1024-sample tails + main launch over 2^30 samples), so that "
-                         "2 x the per-launch figures = one step",
+    one_launch = RND >= "r3"       # round 3: ONE launch per step (the kernel runs the sub-chunks' run-ups itself)
+    alg5 = (1 << 30) * 16 if one_launch else (1 << 29) * 16     # before: the means are over two launches = half a step
+    json.dump({"kernel": ("dsp::iir_scan16_kernel<16, 64, true, false, true>: the one launch of a config-5 step over 8192 "
+                          "sub-chunks of 2^17 samples; the reads above the algorithmic bytes are the 4096-sample run-up "
+                          "in front of each sub-chunk (3.1 %)") if one_launch else
+                         ("dsp::iir_scan16_kernel<16, 64, true, false>: mean over the two launches of a config-5 step "
+                          "(run-up over the sub-chunks' 1024-sample tails + main launch over 2^30 samples), so that "
+                          "2 x the per-launch figures = one step"),
                "source": "profiles/" + RND + "_config5_rocprofv3_summary.txt (PROF_MFMA=1 tools/prof.sh: separate --pmc passes; "
                          "bench.py --workload stream16 --no-cpu)",
                "FETCH_SIZE_KiB_per_launch": f5, "WRITE_SIZE_KiB_per_launch": w5, "correction": CORR,

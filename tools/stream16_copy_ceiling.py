@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""What a plain copy reaches with config 5's access pattern: 1024 rows of 2^20 samples a row apart (the sub-chunks of the
-2^30 stream), one wave per row, 4096-sample pieces (iir_scan16_kernel's segments) -- against the same bytes swept in
-the tiled order (1024 workgroups on one contiguous window per step).  usage: stream16_copy_ceiling.py [log2 n]"""
+"""What a plain copy reaches with config 5's access pattern: 2^30 / n rows of n samples a row apart (the sub-chunks of the
+2^30 stream; 1024 workgroups resident at a time), one wave per row, 4096-sample pieces (iir_scan16_kernel's segments) -- against the same bytes swept in
+the tiled order (1024 workgroups on one contiguous window per step).  usage: stream16_copy_ceiling.py [log2 sub-chunk length]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dsp_amd.cdsp import dspdll
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-nch, n = 1024, 1 << lg
+nch, n = (1 << 30) >> lg, 1 << lg          # always 2^30 samples: rows = consecutive sub-chunks of one stream
 x = torch.empty(nch * n, dtype=torch.float64, device="cuda").uniform_(-1, 1)
 y = torch.empty_like(x)
 s = torch.cuda.current_stream()
