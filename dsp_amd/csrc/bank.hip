@@ -541,8 +541,10 @@ struct RTFilterBank {
             *d_nb = nullptr, *d_na = nullptr, *d_kind = nullptr;
     double *d_coefs = nullptr, *d_pows = nullptr;
     double *d_static_scratch = nullptr;   /* this device's copy of `scratch` (RTFilterBank_updaten_noalloc) */
-    bool stream_rows = false;             /* set by RTFilterStream around one call: the rows are consecutive sub-chunks
-                                             of one stream, the order 9..16 scan kernel runs its own run-ups (BlockIO::runup) */
+    int stream_rows = 0;                  /* set by RTFilterStream around one call: the rows are consecutive sub-chunks
+                                             of one stream, the order 9..16 scan kernel runs its own run-ups
+                                             (BlockIO::runup: 4 = over the whole segment in front of a row, 1 = over
+                                             its last 1024 samples) */
     HostPipe host;                        /* staging rings of RTFilterBank_updaten_host, built on first use */
 };
 
@@ -1986,7 +1988,7 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
         else if (pipe16_enabled() && io.aligned16 && n % kPipe16Seg == 0)
             HIP_TRY(launch_iir_pipe16(g.order, v, io, Pipe16Ext{}, 0, s));   /* orders 9..16, whole segments */
         else {
-            io.runup = bank->stream_rows ? 1 : 0;                   /* (checked above) */
+            io.runup = bank->stream_rows;                           /* (checked above) */
             HIP_TRY(launch_iir_scan(g.order, v, io, s));            /* orders 9..16, any shape */
         }
     }
@@ -2593,9 +2595,9 @@ int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t
          * segment in front of it (no run-up launch, no scratch) */
         HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, nullptr, C, (int)ld,
                                   0, 1, s));
-        sb->main->stream_rows = true;
+        sb->main->stream_rows = M <= kScanSeg / 4 ? 1 : 4;
         rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s);
-        sb->main->stream_rows = false;
+        sb->main->stream_rows = 0;
         if (rc) return rc;
         HIP_TRY(launch_split_finish(g1.d_state, g1.d_fval, g1.d_init, gm.d_state, gm.d_fval, C, (int)ld, s));
         return RTFB_OK;

@@ -17,6 +17,7 @@
  * 16 B/sample, the algorithmic minimum.
  */
 #include <cstdlib>
+#include <type_traits>
 #include "dsp_internal.h"
 #include "kernel_common.h"
 #include "iir_steps.h"
@@ -546,26 +547,57 @@ iir_scan16_kernel(GroupView g, BlockIO io)
      * the passes on the matrix cores alone, no recurrence, nothing stored.  This replaces a run-up LAUNCH over all
      * sub-chunks, which costs more than it saves once a stream is cut into thousands of them. */
     if (io.runup && gi > 0) {
+        /* io.runup = 16-row blocks of the segment in front that are read: 4 (all of it), or 1 (its last 1024
+         * samples, for designs that have forgotten everything older: most have) */
+        const bool whole = io.runup != 1;           /* (wave-uniform) */
+        constexpr int kLastBlock = TG::kLoads - TG::kLoads / 4;     /* loads of rows 48..63 */
+        static_assert(TG::kLoads % 4 == 0, "a 16-row block is a whole number of loads");
+        if (whole) {
 #pragma unroll
-        for (int i = 0; i < TG::kLoads; ++i)
+            for (int i = 0; i < kLastBlock; ++i)
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(src - kSeg + 2 * (i * kWave + lane)));
+        }
+#pragma unroll
+        for (int i = kLastBlock; i < TG::kLoads; ++i)
             pre[i] = stream_load(reinterpret_cast<const d2 *>(src - kSeg + 2 * (i * kWave + lane)));
-        park();
+        if (whole) {
+#pragma unroll
+            for (int i = 0; i < kLastBlock; ++i) {
+                const int p = i * kWave + lane;
+                *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
+                                        (p % TG::kPiecesPerRow) * 16) = pre[i];
+            }
+        }
+#pragma unroll
+        for (int i = kLastBlock; i < TG::kLoads; ++i) {
+            const int p = i * kWave + lane;
+            *reinterpret_cast<d2 *>(smem + (p / TG::kPiecesPerRow) * TG::kRowBytes +
+                                    (p % TG::kPiecesPerRow) * 16) = pre[i];
+        }
+        wave_sync();
         fetch(0);                                   /* the sub-chunk's first segment flies during the run-up */
         const double tail = carry[N];
         d4 acc[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < 4; ++rb) {            /* rows in front of what was read: zero input, zero state */
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[rb][t] = Gt[t] * tail;
         }
         const char *xb = smem + r16 * TG::kRowBytes + q4 * 8;
+        if (whole) {
+#pragma unroll
+            for (int ks = 0; ks < T / 4; ++ks) {
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) {
+                    const double xv = *reinterpret_cast<const double *>(xb + rb * 16 * TG::kRowBytes + ks * 32);
+                    acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gr[ks], xv, acc[rb], 0, 0, 0);
+                }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < T / 4; ++ks) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const double xv = *reinterpret_cast<const double *>(xb + rb * 16 * TG::kRowBytes + ks * 32);
-                acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gr[ks], xv, acc[rb], 0, 0, 0);
-            }
+            const double xv = *reinterpret_cast<const double *>(xb + 3 * 16 * TG::kRowBytes + ks * 32);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gr[ks], xv, acc[3], 0, 0, 0);
         }
         const double cvirt[4] = {0.0, 0.0, 0.0, 0.0};
         switch (nlev) {

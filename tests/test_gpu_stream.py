@@ -160,12 +160,13 @@ def test_stream_from_filter_and_sync_to_host(G):
     fs.close()
 
 
-@pytest.mark.parametrize("design", ["bw8", "lp11"])
+@pytest.mark.parametrize("design", ["bw8", "lp11", "comb10"])
 def test_long_stream_in_short_sub_chunks_with_in_kernel_run_ups(G, design):
     """Streams of orders 9..16 longer than 1024 x 2^17 samples are cut into sub-chunks of 2^17 samples whose start
     states iir_scan16_kernel computes itself (the zero-state response of the 4096 samples in front of each).  Config
-    5's band-pass (numerator taps b[odd] == 0: the even-b instantiation) and an order-11 low-pass (no zero taps):
-    a fresh stream, a ragged continuation, and an in-place call (which must fall back to the run-up launch: the
+    5's band-pass (numerator taps b[odd] == 0: the even-b instantiation; decay length 1024: the run-up reads the
+    last 1024 samples), an order-11 low-pass (no zero taps) and an order-10 comb whose decay length is 4096 (the
+    run-up reads the whole segment): a fresh stream, a ragged continuation, and an in-place call (which must fall back to the run-up launch: the
     samples in front of a sub-chunk would already be outputs) -- all within 1e-12 of the oracle, state included."""
     import torch
     from dsp_amd import bank as gbank
@@ -175,11 +176,15 @@ def test_long_stream_in_short_sub_chunks_with_in_kernel_run_ups(G, design):
     if design == "bw8":
         b, a = _bw8()
         assert all(v == 0.0 for v in b[1::2])
-    else:
+    elif design == "lp11":
         f = dsp.butterworth(11, 0.0, 0.35)
         b, a = np.array(f.b()), np.array(f.a())
+    else:                                              # poles on a circle of radius 0.985: 0.86^(M/10) < 2^-80 from M = 3680
+        a = np.zeros(11); a[0], a[10] = 1.0, -0.86
+        b = np.zeros(11); b[0], b[1], b[10] = 0.2, 0.1, 0.05
     fs = gstream.FilterStream(gbank.iir_design(b, a))
     assert 0 < fs.decay_length <= 4096
+    assert (fs.decay_length > 1024) == (design == "comb10"), fs.decay_length
     ref = orc.iir(b, a)
     pos = 0
     for i, n in enumerate(((1 << 27) + 3 * (1 << 17) + 777, (1 << 27) + (1 << 18), (1 << 27) + (1 << 18))):
