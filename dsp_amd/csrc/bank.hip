@@ -2454,7 +2454,7 @@ constexpr size_t kStreamMaxSplit = 1024;      /* sub-chunks per call at most whi
  * prefetch running across them instead of a wave per sub-chunk: the same 326 600 at 2^17, less at every other
  * length -- not kept).  A run-up LAUNCH over 8191 sub-chunks (one short ragged segment per
  * workgroup, eight rounds of them) costs more than that gains (config 5: 310 000 -> 292 000 Msamples/s), so the
- * scan kernel of orders 9..16 computes the run-ups itself (BlockIO::runup, kernels.hip). */
+ * scan kernel of orders 9..16 computes the run-ups itself (BlockIO::runup, kernels.hip): 332 000. */
 constexpr size_t kStreamChunkTarget = (size_t)1 << 17;
 constexpr size_t kStreamMaxSplitShort = 65536;
 constexpr size_t kScanSeg = (size_t)kWave * kScanT;           /* iir_scan16_kernel's segment: its run-up length */

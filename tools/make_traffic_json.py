@@ -71,8 +71,8 @@ def main():
     one_launch = RND >= "r3"       # round 3: ONE launch per step (the kernel runs the sub-chunks' run-ups itself)
     alg5 = (1 << 30) * 16 if one_launch else (1 << 29) * 16     # before: the means are over two launches = half a step
     json.dump({"kernel": ("dsp::iir_scan16_kernel<16, 64, true, false, true>: the one launch of a config-5 step over 8192 "
-                          "sub-chunks of 2^17 samples; the reads above the algorithmic bytes are the 4096-sample run-up "
-                          "in front of each sub-chunk (3.1 %)") if one_launch else
+                          "sub-chunks of 2^17 samples; the reads above the algorithmic bytes are the 1024-sample run-up "
+                          "in front of each sub-chunk (0.8 %)") if one_launch else
                          ("dsp::iir_scan16_kernel<16, 64, true, false>: mean over the two launches of a config-5 step "
                           "(run-up over the sub-chunks' 1024-sample tails + main launch over 2^30 samples), so that "
                           "2 x the per-launch figures = one step"),
