@@ -2873,15 +2873,19 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         size_t lmin = std::max<size_t>(4 * st->decay, 8192);
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
         size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
-        /* long streams of orders 9..16: more, shorter sub-chunks whose run-ups the kernel does itself (it reads the
-         * segment in front of a sub-chunk: not in place, where that segment may already hold outputs) */
+        /* orders 9..16: the kernel does the run-ups of the sub-chunks itself (no run-up launch: 15-20 us of a call;
+         * it reads the samples in front of a sub-chunk: not in place, where they may already hold outputs), and
+         * long streams are cut into more, shorter sub-chunks */
         bool self_runup = false;
         size_t grain = kStreamGrain;
         if (st->decay && st->decay <= kScanSeg && whole16 && !overlap && scan16_serves(st->one, kScanSeg) &&
-            st->one->groups[0].scan_safe && n / std::max(lmin, kStreamChunkTarget) > kStreamMaxSplit) {
-            C = std::min(kStreamMaxSplitShort, n / std::max(lmin, kStreamChunkTarget));
-            self_runup = true;
-            grain = kScanSeg;
+            st->one->groups[0].scan_safe) {
+            if (n / std::max(lmin, kStreamChunkTarget) > kStreamMaxSplit)
+                C = std::min(kStreamMaxSplitShort, n / std::max(lmin, kStreamChunkTarget));
+            if (C >= kStreamMinSplit) {                 /* (n / C >= lmin >= two segments) */
+                self_runup = true;
+                grain = kScanSeg;
+            }
         }
         bool exact = false;
         if (C < kStreamMinSplit && st->exact_ok && !overlap) {
