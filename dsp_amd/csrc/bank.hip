@@ -3052,9 +3052,24 @@ int RTFilterStream_tail_state(RTFilterStream *st, const double *in, size_t n, do
     if (!ds.ok) return fail(RTFB_EDEVICE, "hipSetDevice failed");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const size_t M = st->decay;
+    const Group &g = st->tail->groups[0];
+    if (M <= kScanSeg && n >= kScanSeg && scan16_serves(st->tail, kScanSeg) && g.scan_safe &&
+        reinterpret_cast<uintptr_t>(in + n) % 16 == 0) {
+        /* orders 9..16: the scan kernel's run-up alone, on the samples in front of in + n (no samples of its own) */
+        BlockIO io;
+        io.out = nullptr;
+        io.ld_out = 0;
+        io.in = in + n;
+        io.ld_in = 0;
+        io.n = 0;
+        io.aligned16 = 1;
+        io.runup = (M <= kScanSeg / 4 ? 1 : 4) | 8;
+        HIP_TRY(launch_iir_scan(g.order, view_of(st->tail, g), io, s));
+        HIP_TRY(launch_state_pack(pack_dev, g.d_state, g.d_fval, g.d_init, g.state_ld, s));
+        return RTFB_OK;
+    }
     int rc = stream_scratch(st, std::max<size_t>(M, 1), s);
     if (rc) return rc;
-    const Group &g = st->tail->groups[0];
     HIP_TRY(hipMemsetAsync(g.d_state, 0, (size_t)g.state_ld * sizeof(double), s));
     HIP_TRY(hipMemsetAsync(g.d_init, 0, sizeof(int32_t), s));
     if ((rc = RTFilterBank_updaten(st->tail, st->d_scratch, M, in + (n - M), M, M, s))) return rc;

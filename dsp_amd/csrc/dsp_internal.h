@@ -79,8 +79,9 @@ struct BlockIO {
     size_t        n;
     int           aligned16;  /* in/out/ld allow 16-byte vector access */
     int           runup = 0;  /* iir_scan16_kernel only (RTFilterStream): the rows are consecutive sub-chunks of one
-                                 stream; every channel but the first starts from the zero-state response of the 4096
-                                 samples in front of its row (kernels.hip).  0 everywhere else. */
+                                 stream; every channel but the first starts from the zero-state response of the
+                                 samples in front of its row (kernels.hip): 4 = the 4096 before it, 1 = the last 1024;
+                                 + 8 = the first channel too.  0 everywhere else. */
 };
 
 /* Chained launches of the pipelined kernel (RTFilterBank_updaten_chained): consecutive blocks of a bank are

@@ -545,11 +545,12 @@ iir_scan16_kernel(GroupView g, BlockIO io)
      * the sub-chunk before): every channel but the first takes its start state from the zero-state response of the
      * whole segment in front of its rows (>= the design's decay length, checked by the host: exact to 2^-80) --
      * the passes on the matrix cores alone, no recurrence, nothing stored.  This replaces a run-up LAUNCH over all
-     * sub-chunks, which costs more than it saves once a stream is cut into thousands of them. */
-    if (io.runup && gi > 0) {
-        /* io.runup = 16-row blocks of the segment in front that are read: 4 (all of it), or 1 (its last 1024
+     * sub-chunks, which costs more than it saves once a stream is cut into thousands of them.  With n == 0 the
+     * kernel is the run-up alone: the state it leaves is the hand-off vector of the samples in front of the row. */
+    if (io.runup && (gi > 0 || (io.runup & 8))) {   /* bit 3: the first channel as well (RTFilterStream_tail_state) */
+        /* io.runup & 7 = 16-row blocks of the segment in front that are read: 4 (all of it), or 1 (its last 1024
          * samples, for designs that have forgotten everything older: most have) */
-        const bool whole = io.runup != 1;           /* (wave-uniform) */
+        const bool whole = (io.runup & 7) != 1;     /* (wave-uniform) */
         constexpr int kLastBlock = TG::kLoads - TG::kLoads / 4;     /* loads of rows 48..63 */
         static_assert(TG::kLoads % 4 == 0, "a 16-row block is a whole number of loads");
         if (whole) {
@@ -609,6 +610,10 @@ iir_scan16_kernel(GroupView g, BlockIO io)
             case 5: scan16_combine<5>(acc, Mr, cvirt); break;
             default: scan16_combine<6>(acc, Mr, cvirt); break;
         }
+        /* end state of the last row -- or, for a hand-off vector (bit 3), of the row before it: the last row then goes
+         * through the recurrence sample by sample (every lane the same arithmetic), which also yields the stream's
+         * last output, RTFilter.filtered_value */
+        const int from = (io.runup & 8) ? kWave - 2 : kWave - 1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             double w0 = acc[0][t], w1 = acc[1][t], w2 = acc[2][t], w3 = acc[3][t];
@@ -616,7 +621,12 @@ iir_scan16_kernel(GroupView g, BlockIO io)
             const double w[4] = {w0, w1, w2, w3};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (4 * t + q < N) carry[4 * t + q] = shfl_f64(w[q], kWave - 1);      /* end state of the last row */
+                if (4 * t + q < N) carry[4 * t + q] = shfl_f64(w[q], from);
+        }
+        if (io.runup & 8) {
+            const double *last = reinterpret_cast<const double *>(smem + (kWave - 1) * TG::kRowBytes);
+#pragma unroll 1
+            for (int k = 0; k < T; ++k) ylast = iir_step_fused<N, kUnitA0, kEvenB>(last[k], carry, b, a);
         }
         need_seed = false;
         wave_sync();

@@ -120,6 +120,12 @@ def test_tail_state_handoff_equals_one_long_run(G):
     r1 = gstream.FilterStream(gbank.iir_design(b, a))
     pack = r0.new_pack()
     assert r0.tail_state(xd[:n], pack)        # rank 0: hand-off vector of its own chunk
+    ref0 = orc.iir(b, a)                      # ... = state, filtered_value, initialized of a filter after that chunk
+    y_ref0 = ref0.updaten(x[:n])
+    pk = pack.cpu().numpy()
+    ns = len(ref0.state)
+    assert np.max(np.abs(pk[:ns] - ref0.state)) <= TOL * max(1.0, np.max(np.abs(ref0.state)))
+    assert abs(pk[-2] - y_ref0[-1]) <= TOL * np.max(np.abs(y_ref0)) and pk[-1] == 0.0
     r1.import_state(pack)                     # rank 1 starts from it ...
     y1 = r1(xd[n:])                           # ... and both filter concurrently
     y0 = r0(xd[:n])
