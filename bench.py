@@ -861,6 +861,27 @@ def main_stream16(args, emit=True):
         elapsed = float(t.item())
     step_ms = [e0.elapsed_time(e1) for e0, e1 in events]
     avg_s = float(np.mean(step_ms)) / 1e3
+    # untimed extra: what a plain copy of the same bytes reaches with the same access pattern -- rows = the stream's
+    # sub-chunks, one workgroup per row, taken in dispatch order (tools/stream16_copy_ceiling.py)
+    copy_gbs = None
+    if world == 1 and not args.no_extra and fs.last_split >= 8 and n % fs.last_split == 0 \
+            and (n // fs.last_split) % 2048 == 0:
+        import ctypes as C
+        from dsp_amd.cdsp import dspdll
+        rows, ln = fs.last_split, n // fs.last_split
+        sp = C.c_void_p(stream.cuda_stream)
+
+        def copy():
+            return dspdll.dsp_copy_rows(C.c_void_p(y.data_ptr()), ln, C.c_void_p(x.data_ptr()), ln, rows, ln, 256, 2048, sp)
+        if copy() == 0:
+            copy()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(stream)
+            for _ in range(4):
+                copy()
+            c1.record(stream)
+            torch.cuda.synchronize()
+            copy_gbs = n * BYTES_PER_SAMPLE / (c0.elapsed_time(c1) / 4 / 1e3) / 1e9
     if rank == 0:
         achieved = n * BYTES_PER_SAMPLE / avg_s / 1e9
         line = {
@@ -883,6 +904,8 @@ def main_stream16(args, emit=True):
                                  "computes their run-ups itself --, two small state kernels) over the step's device "
                                  "time on rank 0; traffic = PMC bytes of that launch "
                                  "(profiles/r3_config5_traffic.json, committed; not re-measured by this run)",
+                         "copy_ceiling_measured": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "step_ms_avg": avg_s * 1e3, "step_ms_min": float(np.min(step_ms))},
         }
         if world == 1 and not args.no_cpu:
