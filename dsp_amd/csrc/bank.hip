@@ -545,6 +545,7 @@ struct RTFilterBank {
                                              of one stream, the order 9..16 scan kernel runs its own run-ups
                                              (BlockIO::runup: 4 = over the whole segment in front of a row, 1 = over
                                              its last 1024 samples) */
+    const double *stream_runup_src = nullptr;   /* with it (in-place streams): BlockIO::runup_src */
     HostPipe host;                        /* staging rings of RTFilterBank_updaten_host, built on first use */
 };
 
@@ -1989,6 +1990,7 @@ static int bank_updaten(RTFilterBank *bank, double *out, size_t ld_out, const do
             HIP_TRY(launch_iir_pipe16(g.order, v, io, Pipe16Ext{}, 0, s));   /* orders 9..16, whole segments */
         else {
             io.runup = bank->stream_rows;                           /* (checked above) */
+            io.runup_src = bank->stream_rows ? bank->stream_runup_src : nullptr;
             HIP_TRY(launch_iir_scan(g.order, v, io, s));            /* orders 9..16, any shape */
         }
     }
@@ -2595,9 +2597,22 @@ int stream_split_piece(RTFilterStream *st, double *out, const double *in, size_t
          * segment in front of it (no run-up launch, no scratch) */
         HIP_TRY(launch_split_seed(gm.d_state, gm.d_fval, gm.d_init, g1.d_state, g1.d_fval, g1.d_init, nullptr, C, (int)ld,
                                   0, 1, s));
+        const double *saved = nullptr;
+        if (in == out) {
+            /* in place: a sub-chunk's last samples may be outputs by the time its successor starts, so the 1024
+             * in front of every sub-chunk are set aside first (8 KiB per sub-chunk; the chooser admits in-place
+             * calls only when that is the whole run-up) */
+            constexpr size_t kQ = kScanSeg / 4;
+            if ((rc = stream_scratch(st, (C - 1) * kQ, s))) return rc;
+            HIP_TRY(hipMemcpy2DAsync(st->d_scratch, kQ * sizeof(double), in + (Lc - kQ), Lc * sizeof(double),
+                                     kQ * sizeof(double), C - 1, hipMemcpyDeviceToDevice, s));
+            saved = st->d_scratch;
+        }
         sb->main->stream_rows = M <= kScanSeg / 4 ? 1 : 4;
+        sb->main->stream_runup_src = saved;
         rc = RTFilterBank_updaten(sb->main, out, Lc, in, Lc, Lc, s);
         sb->main->stream_rows = 0;
+        sb->main->stream_runup_src = nullptr;
         if (rc) return rc;
         HIP_TRY(launch_split_finish(g1.d_state, g1.d_fval, g1.d_init, gm.d_state, gm.d_fval, C, (int)ld, s));
         return RTFB_OK;
@@ -2874,12 +2889,13 @@ int RTFilterStream_updaten(RTFilterStream *st, double *out, const double *in, si
         lmin = (lmin + kStreamGrain - 1) / kStreamGrain * kStreamGrain;
         size_t C = st->decay ? std::min(kStreamMaxSplit, n / lmin) : 0;
         /* orders 9..16: the kernel does the run-ups of the sub-chunks itself (no run-up launch: 15-20 us of a call;
-         * it reads the samples in front of a sub-chunk: not in place, where they may already hold outputs), and
-         * long streams are cut into more, shorter sub-chunks */
+         * it reads the samples in front of a sub-chunk -- in place, where they may already hold outputs, from a
+         * copy set aside beforehand, which is kept to run-ups of 1024 samples), and long streams are cut into more,
+         * shorter sub-chunks */
         bool self_runup = false;
         size_t grain = kStreamGrain;
-        if (st->decay && st->decay <= kScanSeg && whole16 && !overlap && scan16_serves(st->one, kScanSeg) &&
-            st->one->groups[0].scan_safe) {
+        if (st->decay && st->decay <= kScanSeg && whole16 && (!overlap || st->decay <= kScanSeg / 4) &&
+            scan16_serves(st->one, kScanSeg) && st->one->groups[0].scan_safe) {
             if (n / std::max(lmin, kStreamChunkTarget) > kStreamMaxSplit)
                 C = std::min(kStreamMaxSplitShort, n / std::max(lmin, kStreamChunkTarget));
             if (C >= kStreamMinSplit) {                 /* (n / C >= lmin >= two segments) */

@@ -82,6 +82,9 @@ struct BlockIO {
                                  stream; every channel but the first starts from the zero-state response of the
                                  samples in front of its row (kernels.hip): 4 = the 4096 before it, 1 = the last 1024;
                                  + 8 = the first channel too.  0 everywhere else. */
+    const double *runup_src = nullptr;   /* with runup == 1: the last 1024 samples in front of row gi (gi >= 1) were
+                                            copied to runup_src + (gi - 1) * 1024 beforehand (in-place streams, whose
+                                            rows already hold outputs when their successors start) */
 };
 
 /* Chained launches of the pipelined kernel (RTFilterBank_updaten_chained): consecutive blocks of a bank are

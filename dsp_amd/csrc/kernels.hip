@@ -553,14 +553,16 @@ iir_scan16_kernel(GroupView g, BlockIO io)
         const bool whole = (io.runup & 7) != 1;     /* (wave-uniform) */
         constexpr int kLastBlock = TG::kLoads - TG::kLoads / 4;     /* loads of rows 48..63 */
         static_assert(TG::kLoads % 4 == 0, "a 16-row block is a whole number of loads");
+        /* the segment in front of the row -- or (in-place streams) the saved copy of its last quarter */
+        const double *front = (io.runup_src && gi > 0) ? io.runup_src + (size_t)gi * (kSeg / 4) - kSeg : src - kSeg;
         if (whole) {
 #pragma unroll
             for (int i = 0; i < kLastBlock; ++i)
-                pre[i] = stream_load(reinterpret_cast<const d2 *>(src - kSeg + 2 * (i * kWave + lane)));
+                pre[i] = stream_load(reinterpret_cast<const d2 *>(front + 2 * (i * kWave + lane)));
         }
 #pragma unroll
         for (int i = kLastBlock; i < TG::kLoads; ++i)
-            pre[i] = stream_load(reinterpret_cast<const d2 *>(src - kSeg + 2 * (i * kWave + lane)));
+            pre[i] = stream_load(reinterpret_cast<const d2 *>(front + 2 * (i * kWave + lane)));
         if (whole) {
 #pragma unroll
             for (int i = 0; i < kLastBlock; ++i) {

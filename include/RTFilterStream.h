@@ -14,8 +14,8 @@
  * decay length: the smallest power of two with max|A^M| < 2^-80 for the homogeneous recurrence
  * s' = A s of RTIIRFilter_update (ref: src/RTFilter.c:417-433).  What the truncation drops is
  * below 2^-80 of the state, far inside the 1e-12 bar.  (Up to 1024 sub-chunks, the run-ups in a launch of their
- * own; long streams of orders 9..16, out of place: sub-chunks of 2^17 samples whose run-ups the scan kernel computes
- * itself from the 4096 samples in front of each -- one launch)  Designs that decay too slowly for that (or not within
+ * own; orders 9..16: sub-chunks of 2^17 samples at most whose run-ups the scan kernel computes itself from the 1024
+ * or 4096 samples in front of each -- one launch; in place the former are set aside first.)  Designs that decay too slowly for that (or not within
  * 2^20 samples) have their chunk maps composed exactly instead: a first pass from the zero state gives every
  * sub-chunk's affine map s_end = A^Lc s_start + v, the start states follow by composition, a second pass filters
  * (twice the traffic).  Designs that fail the scan conditioning probe, in-place calls without decay and calls too

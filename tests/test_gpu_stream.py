@@ -200,7 +200,9 @@ def test_long_stream_in_short_sub_chunks_with_in_kernel_run_ups(G, design):
         if i == 2:
             fs.updaten_ptr(xd.data_ptr(), xd.data_ptr(), n)
             yd = xd
-            assert fs.last_split == 1024, fs.last_split
+            # in place: short sub-chunks too where the run-up is the last 1024 samples (set aside before the launch);
+            # the comb's whole-segment run-ups keep the long sub-chunks and the run-up launch
+            assert (fs.last_split == 1024) == (design == "comb10"), fs.last_split
         else:
             yd = fs(xd)
             assert fs.last_split > 1024, fs.last_split
